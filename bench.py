@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward+adjoint gradient evaluations per second (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sh23|kdyn|shb23] [--no-cpu-baseline]
+
+One "step" = one gradient evaluation = one forward solve (J) + one adjoint solve (grad J) at the same X over the
+full time window, inputs already resident in HBM.  Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None, help="sh23 | shb23 | kdyn (default: the largest single-GPU config built)")
+    ap.add_argument("--npts", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=None, help="override N_ITERS (the result is then flagged as reduced)")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_sh23(Npts, dt, n_iters, X, budget_s=10.0):
+    """Oracle (NumPy/pocketfft restatement, 1 thread — the reference forces OMP_NUM_THREADS=1) timed on the host."""
+    from oracle.sh23 import SH23Oracle
+    o = SH23Oracle(Npts, dt=dt, N_ITERS=n_iters)
+    o.forward([X]); o.adjoint([X])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 200:
+        o.forward([X]); o.adjoint([X]); n += 1
+    el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "gradient evals/s", "cores": 1, "kind": "port",
+            "sample": "%d full forward+adjoint evaluations of the same workload (NumPy restatement of the Dedalus path)" % n}
+
+
+def bench_sh23(a, torch, rank, world):
+    from spheremanopt_amd import sh23
+    Npts = a.npts or 256
+    dt, n_iters = 0.1, a.iters or 500
+    steps = a.steps if a.steps is not None else 200
+    warm = a.warmup if a.warmup is not None else 20
+    dom, X = sh23.Generate_IC(0.0725, Npts=Npts, seed=42 + rank)
+    dom.device = torch.cuda.current_device()
+    ctx = dom.context(dt, n_iters, batch=a.batch)
+    Xd = torch.from_numpy(np.tile(X, a.batch)).cuda()
+    Gd = torch.empty_like(Xd)
+    for _ in range(warm):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    tim = ctx.timing()
+    dom_k = max(tim, key=lambda t: t["total_ms"])
+    avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
+            "note": "latency-bound config: one workgroup per problem, %d dependent steps per launch; us/step = %.3f"
+                    % (n_iters, avg_ms * 1e3 / n_iters)}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    cfg = {"workload": "Swift-Hohenberg 1D Fourier Npts=%d T=%g dt=%g discrete adjoint" % (Npts, dt * n_iters, dt),
+           "grid": 2 * Npts, "n_iters": n_iters, "batch": a.batch, "parallelism": "replicas only (x%d)" % world}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_sh23(Npts, dt, n_iters, X)
+    return steps, warm, el, a.batch, roof, cfg, cpu
+
+
+def main():
+    a = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl")
+    wl = a.workload or "sh23"
+    if wl == "sh23":
+        steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
+    else:
+        raise SystemExit("workload %s not built yet" % wl)
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        total = steps * per_step_units * world
+        out = {"metric": "forward+adjoint gradient evals/sec", "value": total / el, "unit": "gradient evals/s",
+               "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+/*
+ * smo.h — C-ABI of the MI355X-native forward/adjoint spectral-solve hot path of SphereManOpt.
+ *
+ * The reference is pure Python; its optimiser (Sphere_Grad_Descent.py:692) reaches the hot path only through
+ * three callbacks  f / Grad_f / Inner_Product  (SURVEY.md section 8b).  This header is what those callbacks
+ * bind to (ctypes stub: INTEGRATION.md; shipped binding: spheremanopt_amd/_capi.py):
+ *
+ *   smo_create    <- per-call solver construction the reference repeats inside every f / Grad_f:
+ *                    FWD_Solve_Build_Lin   FWD_Solve_SH23.py:279-332, FWD_Solve_KDyn.py:362-450,
+ *                    LBVP build            FWD_Solve_SHB23.py:563-587;  GEN_BUFFER (snapshot stack)
+ *                    FWD_Solve_SH23.py:238-272, FWD_Solve_KDyn.py:319-355, FWD_Solve_SHB23.py:270-314
+ *   smo_forward   <- FWD_Solve_IVP_Lin      FWD_Solve_SH23.py:409-545, FWD_Solve_KDyn.py:529-689,
+ *                    FWD_Solve_IVP_Discrete FWD_Solve_SHB23.py:525-678          (returns the minimised value -J)
+ *   smo_adjoint   <- ADJ_Solve_IVP_Lin      FWD_Solve_SH23.py:598-729 (+Compatib_Cond :552-596),
+ *                                           FWD_Solve_KDyn.py:766-1004 (+Compatib_Cond :696-764),
+ *                    ADJ_Solve_IVP_Discrete FWD_Solve_SHB23.py:796-920
+ *   smo_inner     <- Inner_Prod             FWD_Solve_SH23.py:158-172, Inner_Prod_3 FWD_Solve_KDyn.py:173-181,
+ *                    Inner_Prod_Discrete    FWD_Solve_SHB23.py:189-193
+ *
+ * Conventions
+ *   - every function returns SMO_OK (0) or an error code; smo_last_error() gives the message (thread local).
+ *   - vectors are the reference's flat float64 grid vectors (Vec_to_Field / Field_to_Vec layouts):
+ *       SH23 : 1 component, G = 2*npts values on the scale-2 Fourier grid
+ *       SHB23: 1 component, npts values on the ascending Gauss-Chebyshev grid
+ *       KDYN : 2 components (B0, U), each 3*G^3 (x,y,z parts concatenated, each C-ordered [x][y][z]), G = 3*npts/2
+ *   - "_dev" entry points take pointers into the HBM of the context's device (no copies); the plain ones take
+ *     caller-owned host buffers and stage them through context-owned device buffers.
+ *   - all entry points are synchronous (return after the context's stream has drained).
+ *   - smo_adjoint replays the snapshot stack filled by the last smo_forward of the same context and returns
+ *     SMO_ERR_STATE if there was none (the reference's hidden contract).
+ *   - `batch` > 1 runs that many independent 1-D problems per call (SH23/SHB23 only): vectors are then
+ *     [batch][len] and J / inner results are arrays of `batch` doubles.
+ *   - one host thread per context; contexts are independent.
+ *   - There is NO CPU fallback: without a usable HIP device smo_create fails with SMO_ERR_NO_DEVICE.
+ */
+#ifndef SMO_H_
+#define SMO_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smo_ctx smo_ctx;
+
+enum { SMO_OK = 0, SMO_ERR_ARG = 1, SMO_ERR_NO_DEVICE = 2, SMO_ERR_HIP = 3, SMO_ERR_STATE = 4, SMO_ERR_NOMEM = 5,
+       SMO_ERR_UNSUPPORTED = 6 };
+
+enum { SMO_SH23 = 1, SMO_SHB23 = 2, SMO_KDYN = 3 };            /* smo_config.kind */
+enum { SMO_COST_FINAL = 0, SMO_COST_INTEGRATED = 1 };           /* smo_config.cost (KDYN) */
+enum { SMO_ADJ_DISCRETE = 0, SMO_ADJ_CONTINUOUS = 1 };          /* `adjoint_type` argument */
+
+typedef struct smo_config {
+    int    kind;        /* SMO_SH23 | SMO_SHB23 | SMO_KDYN */
+    int    npts;        /* Npts as the reference's Generate_IC receives it (SH23 256, SHB23 512, KDYN 128) */
+    double x0, x1;      /* interval of every axis: SH23 (0,12pi), SHB23 (-20,20), KDYN (0,2pi) */
+    double dt;          /* time step */
+    int    n_iters;     /* N_ITERS (the forward solve executes N_ITERS+1 steps for SH23/KDYN, like the reference) */
+    double param;       /* SH23/SHB23: a (-0.3 / -0.1);  KDYN: Rm */
+    int    cost;        /* KDYN: SMO_COST_FINAL | SMO_COST_INTEGRATED */
+    int    batch;       /* independent problems per call (>=1; KDYN: 1) */
+    int    device;      /* HIP device ordinal */
+    /* slab decomposition of the 3-D case (one process per GPU; the exchange itself is done by the host layer):  */
+    int    rank;        /* this process' slab index   (0 when world == 1) */
+    int    world;       /* number of slabs            (1 = single GPU) */
+} smo_config;
+
+/* ---- life cycle ------------------------------------------------------------------------------------------- */
+int         smo_create(const smo_config* cfg, smo_ctx** out);
+void        smo_destroy(smo_ctx* ctx);
+const char* smo_last_error(void);
+const char* smo_version(void);
+int         smo_device_count(int* count);                      /* never initialises a device */
+
+/* ---- geometry --------------------------------------------------------------------------------------------- */
+int smo_ncomp(const smo_ctx* ctx);                              /* number of norm-constrained vectors (1 or 2) */
+int smo_vec_len(const smo_ctx* ctx, size_t* len);               /* doubles per component (per batch member) */
+int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* size of the HBM-resident snapshot stack */
+
+/* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */
+int smo_forward(smo_ctx* ctx, const double* const* X, double* J);
+int smo_adjoint(smo_ctx* ctx, const double* const* X, int adjoint_type, double* const* grad);
+int smo_inner(smo_ctx* ctx, const double* x, const double* y, double* out);
+
+/* ---- the three callbacks, device-resident buffers ------------------------------------------------------------ */
+int smo_forward_dev(smo_ctx* ctx, const double* const* X_dev, double* J_host);
+int smo_adjoint_dev(smo_ctx* ctx, const double* const* X_dev, int adjoint_type, double* const* grad_dev);
+int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double* out_host);
+
+/* ---- introspection used by the parity tests and the benchmark ------------------------------------------------ */
+/* Copy snapshot `index` (0..n_iters) of batch member `b` to the host in the reference's GEN_BUFFER element order:
+ * SH23 complex128[Nc]; SHB23 float64[N]; KDYN complex128[3][a][m][m].  `out` receives smo_snapshot_len doubles. */
+int smo_snapshot_len(const smo_ctx* ctx, size_t* ndoubles);
+int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out);
+
+/* HIP-event timing of the kernels launched by the context (measured on the context's stream).
+ * smo_timing_enable(ctx, 1) resets the accumulators; smo_timing_get returns, for kernel class `k`
+ * (0 <= k < smo_timing_classes), its name, number of launches, total milliseconds and the ALGORITHMIC bytes
+ * one launch moves (DESIGN.md section "kernels"), so  achieved GB/s = bytes * launches / ms / 1e6. */
+int         smo_timing_enable(smo_ctx* ctx, int on);
+int         smo_timing_classes(const smo_ctx* ctx);
+int         smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms,
+                           double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMO_H_ */

@@ -1,0 +1,198 @@
+"""ctypes binding of libsmo.so (C-ABI: include/smo.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable the calls raise.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C spheremanopt_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmo.so")
+
+SMO_SH23, SMO_SHB23, SMO_KDYN = 1, 2, 3
+COST = {"Final": 0, "Integrated": 1}
+ADJOINT = {"Discrete": 0, "Continuous": 1}
+ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO_ERR_STATE", 5: "SMO_ERR_NOMEM",
+             6: "SMO_ERR_UNSUPPORTED"}
+
+EXPORTS = [
+    "smo_create", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
+    "smo_stack_bytes", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
+    "smo_snapshot_len", "smo_snapshot_read", "smo_timing_enable", "smo_timing_classes", "smo_timing_get",
+]
+
+
+class SmoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, "error %d" % code), msg))
+        self.code = code
+
+
+class smo_config(C.Structure):
+    _fields_ = [("kind", C.c_int), ("npts", C.c_int), ("x0", C.c_double), ("x1", C.c_double), ("dt", C.c_double),
+                ("n_iters", C.c_int), ("param", C.c_double), ("cost", C.c_int), ("batch", C.c_int), ("device", C.c_int),
+                ("rank", C.c_int), ("world", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsmo.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsmo.so not found at %s — the HIP extension is not built (run __graft_entry__.build()); "
+                           "spheremanopt_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    pp = C.POINTER(C.c_void_p)
+    L.smo_last_error.restype = C.c_char_p
+    L.smo_version.restype = C.c_char_p
+    L.smo_device_count.argtypes = [ip]
+    L.smo_create.argtypes = [C.POINTER(smo_config), pp]
+    L.smo_destroy.argtypes = [vp]
+    L.smo_destroy.restype = None
+    L.smo_ncomp.argtypes = [vp]
+    L.smo_vec_len.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.smo_stack_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.smo_snapshot_len.argtypes = [vp, C.POINTER(C.c_size_t)]
+    for name in ("smo_forward", "smo_forward_dev"):
+        getattr(L, name).argtypes = [vp, pp, dp]
+    for name in ("smo_adjoint", "smo_adjoint_dev"):
+        getattr(L, name).argtypes = [vp, pp, C.c_int, pp]
+    for name in ("smo_inner", "smo_inner_dev"):
+        getattr(L, name).argtypes = [vp, vp, vp, dp]
+    L.smo_snapshot_read.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.smo_timing_enable.argtypes = [vp, C.c_int]
+    L.smo_timing_classes.argtypes = [vp]
+    L.smo_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SmoError(rc, lib().smo_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().smo_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def _dev_ptr(t):
+    """Device address of a torch tensor (or a plain int)."""
+    return int(t) if isinstance(t, int) else int(t.data_ptr())
+
+
+class Context:
+    """Owner of one smo_ctx (device buffers, twiddles, the HBM snapshot stack)."""
+
+    def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1):
+        cfg = smo_config(kind, int(npts), float(interval[0]), float(interval[1]), float(dt), int(n_iters), float(param),
+                         COST[cost] if isinstance(cost, str) else int(cost), int(batch), int(device), int(rank), int(world))
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _check(lib().smo_create(C.byref(cfg), C.byref(self._h)))
+        self.ncomp = lib().smo_ncomp(self._h)
+        n = C.c_size_t()
+        _check(lib().smo_vec_len(self._h, C.byref(n)))
+        self.vec_len = n.value
+        _check(lib().smo_stack_bytes(self._h, C.byref(n)))
+        self.stack_bytes = n.value
+        _check(lib().smo_snapshot_len(self._h, C.byref(n)))
+        self.snapshot_len = n.value
+        self.batch = int(batch)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().smo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer entry points --------------------------------------------------------------------------------
+    def _host_vecs(self, X):
+        vs = [np.ascontiguousarray(np.asarray(X[c], dtype=np.float64)).reshape(-1) for c in range(self.ncomp)]
+        for v in vs:
+            if v.size != self.vec_len * self.batch:
+                raise ValueError("vector has %d entries, context expects %d" % (v.size, self.vec_len * self.batch))
+        return vs
+
+    def forward(self, X):
+        vs = self._host_vecs(X)
+        J = np.zeros(self.batch)
+        _check(lib().smo_forward(self._h, _ptr_array([v.ctypes.data for v in vs]), J.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(J[0]) if self.batch == 1 else J
+
+    def adjoint(self, X=None, adjoint_type="Discrete"):
+        grads = [np.empty(self.vec_len * self.batch) for _ in range(self.ncomp)]
+        if X is None:
+            xp = _ptr_array([None] * self.ncomp)
+        else:
+            vs = self._host_vecs(X)
+            xp = _ptr_array([v.ctypes.data for v in vs])
+        _check(lib().smo_adjoint(self._h, xp, ADJOINT[adjoint_type], _ptr_array([g.ctypes.data for g in grads])))
+        return grads
+
+    def inner(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if x.size != self.vec_len * self.batch or y.size != x.size:
+            raise ValueError("inner: vectors have %d/%d entries, context expects %d" % (x.size, y.size, self.vec_len * self.batch))
+        out = np.zeros(self.batch)
+        _check(lib().smo_inner(self._h, x.ctypes.data, y.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(out[0]) if self.batch == 1 else out
+
+    # -- device-resident entry points (torch tensors on the context's device, or raw addresses) ------------------------
+    def forward_dev(self, X):
+        J = np.zeros(self.batch)
+        _check(lib().smo_forward_dev(self._h, _ptr_array([_dev_ptr(x) for x in X]), J.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(J[0]) if self.batch == 1 else J
+
+    def adjoint_dev(self, X, grads, adjoint_type="Discrete"):
+        _check(lib().smo_adjoint_dev(self._h, _ptr_array([_dev_ptr(x) for x in X]), ADJOINT[adjoint_type],
+                                     _ptr_array([_dev_ptr(g) for g in grads])))
+        return grads
+
+    def inner_dev(self, x, y):
+        out = np.zeros(self.batch)
+        _check(lib().smo_inner_dev(self._h, _dev_ptr(x), _dev_ptr(y), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(out[0]) if self.batch == 1 else out
+
+    # -- introspection ------------------------------------------------------------------------------------------------
+    def snapshot(self, index, b=0):
+        out = np.empty(self.snapshot_len)
+        _check(lib().smo_snapshot_read(self._h, int(b), int(index), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def timing_enable(self, on=True):
+        _check(lib().smo_timing_enable(self._h, 1 if on else 0))
+
+    def timing(self):
+        res = []
+        for k in range(lib().smo_timing_classes(self._h)):
+            name = C.c_char_p()
+            n = C.c_longlong()
+            ms = C.c_double()
+            by = C.c_double()
+            _check(lib().smo_timing_get(self._h, k, C.byref(name), C.byref(n), C.byref(ms), C.byref(by)))
+            res.append({"kernel": name.value.decode(), "launches": n.value, "total_ms": ms.value, "bytes_per_launch": by.value})
+        return res

@@ -1,0 +1,172 @@
+// extern "C" surface of libsmo (declarations and reference citations: include/smo.h).
+#include "smo_common.hpp"
+
+using smo::Context;
+
+struct smo_ctx {
+    Context* impl;
+};
+
+#define CHECK_CTX(c)                                  \
+    do {                                              \
+        if (!(c) || !(c)->impl) {                     \
+            smo::set_error("null context");           \
+            return SMO_ERR_ARG;                       \
+        }                                             \
+    } while (0)
+
+extern "C" {
+
+const char* smo_last_error(void) { return smo::last_error(); }
+const char* smo_version(void) { return "libsmo 0.1.0 (gfx950)"; }
+
+int smo_device_count(int* count) {
+    if (!count) return SMO_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return SMO_OK;
+}
+
+int smo_create(const smo_config* cfg, smo_ctx** out) {
+    if (!cfg || !out) { smo::set_error("smo_create: null argument"); return SMO_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->batch < 1 || cfg->n_iters < 1 || cfg->npts < 4 || !(cfg->dt > 0) || !(cfg->x1 > cfg->x0) || cfg->world < 1 ||
+        cfg->rank < 0 || cfg->rank >= cfg->world) {
+        smo::set_error("smo_create: bad config (npts=%d n_iters=%d dt=%g batch=%d interval=[%g,%g] rank=%d/%d)", cfg->npts,
+                       cfg->n_iters, cfg->dt, cfg->batch, cfg->x0, cfg->x1, cfg->rank, cfg->world);
+        return SMO_ERR_ARG;
+    }
+    Context* c = nullptr;
+    switch (cfg->kind) {
+        case SMO_SH23: c = smo::make_sh23(*cfg); break;
+        case SMO_SHB23: c = smo::make_shb23(*cfg); break;
+        case SMO_KDYN: c = smo::make_kdyn(*cfg); break;
+        default: smo::set_error("smo_create: unknown kind %d", cfg->kind); return SMO_ERR_ARG;
+    }
+    if (!c) return SMO_ERR_UNSUPPORTED;      // message set by the factory
+    int rc = c->init();
+    if (rc != SMO_OK) { delete c; return rc; }
+    *out = new smo_ctx{c};
+    return SMO_OK;
+}
+
+void smo_destroy(smo_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->impl) {
+        (void)hipSetDevice(ctx->impl->cfg.device);
+        delete ctx->impl;
+    }
+    delete ctx;
+}
+
+int smo_ncomp(const smo_ctx* ctx) { return (ctx && ctx->impl) ? ctx->impl->n_comp : 0; }
+
+int smo_vec_len(const smo_ctx* ctx, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!len) return SMO_ERR_ARG;
+    *len = ctx->impl->vec_len;
+    return SMO_OK;
+}
+int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes) {
+    CHECK_CTX(ctx);
+    if (!bytes) return SMO_ERR_ARG;
+    *bytes = ctx->impl->stack_bytes;
+    return SMO_OK;
+}
+
+static int check_vecs(const smo_ctx* ctx, const double* const* X, const char* who) {
+    if (!X) { smo::set_error("%s: null vector list", who); return SMO_ERR_ARG; }
+    for (int c = 0; c < ctx->impl->n_comp; ++c)
+        if (!X[c]) { smo::set_error("%s: component %d is null", who, c); return SMO_ERR_ARG; }
+    return SMO_OK;
+}
+
+int smo_forward(smo_ctx* ctx, const double* const* X, double* J) {
+    CHECK_CTX(ctx);
+    SMO_TRY(check_vecs(ctx, X, "smo_forward"));
+    if (!J) return SMO_ERR_ARG;
+    return ctx->impl->forward_host(X, J);
+}
+int smo_forward_dev(smo_ctx* ctx, const double* const* X, double* J) {
+    CHECK_CTX(ctx);
+    SMO_TRY(check_vecs(ctx, X, "smo_forward_dev"));
+    if (!J) return SMO_ERR_ARG;
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->forward_dev(X, J);
+}
+
+static int check_adjoint(smo_ctx* ctx, int adjoint_type, double* const* grad) {
+    if (adjoint_type != SMO_ADJ_DISCRETE && adjoint_type != SMO_ADJ_CONTINUOUS) {
+        smo::set_error("smo_adjoint: adjoint_type %d", adjoint_type);
+        return SMO_ERR_ARG;
+    }
+    if (!ctx->impl->have_forward) {
+        smo::set_error("smo_adjoint: no forward solve on this context yet (the adjoint replays its snapshot stack)");
+        return SMO_ERR_STATE;
+    }
+    return check_vecs(ctx, grad, "smo_adjoint(grad)");
+}
+int smo_adjoint(smo_ctx* ctx, const double* const* X, int adjoint_type, double* const* grad) {
+    CHECK_CTX(ctx);
+    SMO_TRY(check_adjoint(ctx, adjoint_type, grad));
+    return ctx->impl->adjoint_host(X, adjoint_type, grad);
+}
+int smo_adjoint_dev(smo_ctx* ctx, const double* const* X, int adjoint_type, double* const* grad) {
+    CHECK_CTX(ctx);
+    SMO_TRY(check_adjoint(ctx, adjoint_type, grad));
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->adjoint_dev(X, adjoint_type, grad);
+}
+
+int smo_inner(smo_ctx* ctx, const double* x, const double* y, double* out) {
+    CHECK_CTX(ctx);
+    if (!x || !y || !out) { smo::set_error("smo_inner: null argument"); return SMO_ERR_ARG; }
+    return ctx->impl->inner_host(x, y, out);
+}
+int smo_inner_dev(smo_ctx* ctx, const double* x, const double* y, double* out) {
+    CHECK_CTX(ctx);
+    if (!x || !y || !out) { smo::set_error("smo_inner_dev: null argument"); return SMO_ERR_ARG; }
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->inner_dev(x, y, out);
+}
+
+int smo_snapshot_len(const smo_ctx* ctx, size_t* n) {
+    CHECK_CTX(ctx);
+    if (!n) return SMO_ERR_ARG;
+    *n = ctx->impl->snapshot_doubles;
+    return SMO_OK;
+}
+int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out) {
+    CHECK_CTX(ctx);
+    if (!out || b < 0 || b >= ctx->impl->cfg.batch || index < 0 || index > ctx->impl->cfg.n_iters) {
+        smo::set_error("smo_snapshot_read: bad argument (b=%d index=%d)", b, index);
+        return SMO_ERR_ARG;
+    }
+    if (!ctx->impl->have_forward) { smo::set_error("smo_snapshot_read: no forward solve yet"); return SMO_ERR_STATE; }
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->snapshot_read(b, index, out);
+}
+
+int smo_timing_enable(smo_ctx* ctx, int on) {
+    CHECK_CTX(ctx);
+    ctx->impl->timing.reset();
+    ctx->impl->timing.on = (on != 0);
+    return SMO_OK;
+}
+int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->timing.cls.size() : 0; }
+int smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms, double* bytes_per_launch) {
+    CHECK_CTX(ctx);
+    auto& t = ctx->impl->timing;
+    if (k < 0 || k >= (int)t.cls.size()) { smo::set_error("smo_timing_get: class %d", k); return SMO_ERR_ARG; }
+    (void)hipSetDevice(ctx->impl->cfg.device);
+    (void)hipStreamSynchronize(ctx->impl->stream);
+    t.flush();
+    if (name) *name = t.cls[k].name.c_str();
+    if (launches) *launches = t.cls[k].launches;
+    if (total_ms) *total_ms = t.cls[k].total_ms;
+    if (bytes_per_launch) *bytes_per_launch = t.cls[k].bytes_per_launch;
+    return SMO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// LDS-staged Stockham autosort FFT for gfx950, complex128.
+//
+// A length-L transform is a chain of decimation-in-frequency Stockham stages of radix 4, then 2, then 3
+// (L = 4^a 2^b 3^c, b,c in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..384).  Stage invariant n*s == L:
+//     y[q + s*(R*p + j)] = w_n^{p*j} * sum_k x[q + s*(p + k*n/R)] * w_R^{j*k},  0 <= p < n/R, 0 <= q < s
+// so (i) the R inputs of consecutive butterflies are consecutive 16-byte elements (conflict-free ds_read_b128 /
+// coalesced global loads) and (ii) in the last stage p == 0: no twiddles, outputs of consecutive butterflies
+// are consecutive.  Passes therefore read global memory in the first stage and write it in the last one;
+// only the stages in between go through LDS (ping-pong between two buffers, one barrier per stage).
+//
+// The twiddle of output j is w_L^{p*s*j}; p*s*j < L, so one table tw[k] = exp(-2 pi i k / L) serves every stage.
+#pragma once
+#include "smo_common.hpp"
+
+namespace smo {
+
+constexpr __host__ __device__ int radix_of(int n) { return (n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : 3); }
+constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + stage_count(n / radix_of(n)); }
+constexpr bool fft_length_ok(int n) {
+    while (n % 4 == 0) n /= 4;
+    if (n % 2 == 0) n /= 2;
+    if (n % 3 == 0) n /= 3;
+    return n == 1;
+}
+
+// ---- radix butterflies (forward: e^{-i..}; INV: conjugate) ------------------------------------------------
+template <bool INV> __device__ __forceinline__ cplx rot90(cplx a) { return INV ? mul_i(a) : mul_mi(a); }   // * (-/+ i)
+
+template <int R, bool INV> struct Butterfly;
+template <bool INV> struct Butterfly<2, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[2]) {
+        cplx a = v[0], b = v[1];
+        v[0] = a + b; v[1] = a - b;
+    }
+};
+template <bool INV> struct Butterfly<3, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[3]) {
+        const double S60 = 0.86602540378443864676372317075294;
+        cplx t = v[1] + v[2];
+        cplx m = mk(v[0].re - 0.5 * t.re, v[0].im - 0.5 * t.im);
+        cplx d = S60 * (v[1] - v[2]);
+        cplx r = rot90<INV>(d);
+        v[0] = v[0] + t; v[1] = m + r; v[2] = m - r;
+    }
+};
+template <bool INV> struct Butterfly<4, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[4]) {
+        cplx t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = rot90<INV>(v[1] - v[3]);
+        v[0] = t0 + t2; v[1] = t1 + t3; v[2] = t0 - t2; v[3] = t1 - t3;
+    }
+};
+
+template <bool INV> __device__ __forceinline__ cplx twmul(cplx a, cplx w) { return INV ? mul_conj(a, w) : a * w; }
+
+// One butterfly of the stage (L, N = current sub-length, S = stride), index j in [0, L/R):
+// loads through `ld(pos)`, stores through `st(pos, value)`, pos in [0, L).
+template <int L, int N, int S, bool INV, class Load, class Store>
+__device__ __forceinline__ void stage_butterfly(int j, const cplx* __restrict__ tw, Load ld, Store st) {
+    constexpr int R = radix_of(N);
+    constexpr int M = N / R;
+    const int p = j / S, q = j - p * S;          // S is a compile-time constant: shifts for 4^k
+    cplx v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = ld(q + S * (p + k * M));
+    Butterfly<R, INV>::run(v);
+    st(q + S * (R * p), v[0]);
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+        cplx o = v[k];
+        if (M > 1) o = twmul<INV>(o, tw[p * S * k]);
+        st(q + S * (R * p + k), o);
+    }
+}
+
+// ---- whole-transform drivers ----------------------------------------------------------------------------
+// NB FFTs of length L, leading dimension LD (>= L) in two LDS buffers; `nthr` threads cooperate.
+// The caller provides first-stage loads  ld0(b, pos)  and last-stage stores  stN(b, pos, value)
+// (typically global memory with zero-padding / truncation folded in).  Contains the barriers it needs,
+// including one at the end of the last LDS-reading stage only if `final_barrier`.
+template <int L, int N, int S, bool INV> struct MidStages {
+    // runs the stages whose sub-length is N (> radix, i.e. not the last), LDS -> LDS, then recurses
+    template <class StoreN>
+    static __device__ __forceinline__ void run(cplx* cur, cplx* nxt, const cplx* tw, int NB, int LD, int tid, int nthr,
+                                               StoreN stN) {
+        constexpr int R = radix_of(N);
+        constexpr int PER = L / R;
+        if constexpr (N / R == 1) {
+            // last stage: LDS -> caller's store
+            for (int t = tid; t < NB * PER; t += nthr) {
+                const int b = t / PER, j = t - b * PER;
+                const cplx* x = cur + b * LD;
+                stage_butterfly<L, N, S, INV>(j, tw, [&](int pos) { return x[pos]; },
+                                              [&](int pos, cplx v) { stN(b, pos, v); });
+            }
+        } else {
+            for (int t = tid; t < NB * PER; t += nthr) {
+                const int b = t / PER, j = t - b * PER;
+                const cplx* x = cur + b * LD;
+                cplx* y = nxt + b * LD;
+                stage_butterfly<L, N, S, INV>(j, tw, [&](int pos) { return x[pos]; }, [&](int pos, cplx v) { y[pos] = v; });
+            }
+            __syncthreads();
+            MidStages<L, N / R, S * R, INV>::run(nxt, cur, tw, NB, LD, tid, nthr, stN);
+        }
+    }
+};
+
+template <int L, bool INV, class Load0, class StoreN>
+__device__ __forceinline__ void fft_batch(cplx* bufA, cplx* bufB, const cplx* tw, int NB, int LD, int tid, int nthr,
+                                          Load0 ld0, StoreN stN) {
+    constexpr int R0 = radix_of(L);
+    constexpr int PER = L / R0;
+    static_assert(L / R0 > 1, "transform needs at least two stages");
+    // first stage: caller's load -> LDS bufA
+    for (int t = tid; t < NB * PER; t += nthr) {
+        const int b = t / PER, j = t - b * PER;
+        cplx* y = bufA + b * LD;
+        stage_butterfly<L, L, 1, INV>(j, tw, [&](int pos) { return ld0(b, pos); }, [&](int pos, cplx v) { y[pos] = v; });
+    }
+    __syncthreads();
+    MidStages<L, L / R0, R0, INV>::run(bufA, bufB, tw, NB, LD, tid, nthr, stN);
+}
+
+}  // namespace smo

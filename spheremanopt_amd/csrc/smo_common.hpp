@@ -1,0 +1,144 @@
+// Shared host-side plumbing of libsmo: error reporting, device buffers, the context base class and
+// HIP-event kernel timing.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smo.h"
+
+namespace smo {
+
+// ---------------------------------------------------------------------------------------------------------
+// complex128 as a plain 16-byte pair (one ds_read_b128 / global_load_dwordx4 per element)
+// ---------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) cplx {
+    double re, im;
+};
+__host__ __device__ inline cplx mk(double r, double i) { cplx c; c.re = r; c.im = i; return c; }
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return mk(a.re + b.re, a.im + b.im); }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return mk(a.re - b.re, a.im - b.im); }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__host__ __device__ inline cplx operator*(double s, cplx a) { return mk(s * a.re, s * a.im); }
+__host__ __device__ inline cplx conj(cplx a) { return mk(a.re, -a.im); }
+__host__ __device__ inline cplx mul_i(cplx a) { return mk(-a.im, a.re); }        //  i * a
+__host__ __device__ inline cplx mul_mi(cplx a) { return mk(a.im, -a.re); }       // -i * a
+__host__ __device__ inline cplx mul_conj(cplx a, cplx w) {                       //  a * conj(w)
+    return mk(a.re * w.re + a.im * w.im, a.im * w.re - a.re * w.im);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define SMO_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            smo::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SMO_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define SMO_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != SMO_OK) return rc_; \
+    } while (0)
+
+// device allocation that records itself for release in the context destructor
+struct DevPool {
+    std::vector<void*> ptrs;
+    size_t total = 0;
+    int alloc(void** p, size_t bytes);
+    template <class T> int alloc(T** p, size_t n) { return alloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
+    template <class T> int upload(T** p, const std::vector<T>& h, hipStream_t s) {
+        SMO_TRY(alloc(p, h.size()));
+        SMO_HIP(hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        SMO_HIP(hipStreamSynchronize(s));
+        return SMO_OK;
+    }
+    void release();
+};
+
+// exp(-2 pi i k / L), k = 0..L-1, evaluated in long double
+std::vector<cplx> twiddles(int L);
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel timing: one accumulator per kernel class, HIP events recorded on the context's stream
+// ---------------------------------------------------------------------------------------------------------
+struct TimingClass {
+    std::string name;
+    double bytes_per_launch = 0;     // algorithmic bytes of ONE launch
+    long long launches = 0;
+    double total_ms = 0;
+};
+
+class Timing {
+public:
+    bool on = false;
+    std::vector<TimingClass> cls;
+    int add_class(const char* name, double bytes) { cls.push_back({name, bytes, 0, 0.0}); return (int)cls.size() - 1; }
+    void reset();
+    void begin(int k, hipStream_t s);
+    void end(int k, hipStream_t s);
+    int flush();                      // resolve pending event pairs (after a stream sync)
+    ~Timing();
+private:
+    struct Pending { int k; hipEvent_t a, b; };
+    std::vector<Pending> pend;
+    std::vector<hipEvent_t> free_ev;
+    hipEvent_t get();
+};
+
+struct ScopedTimer {
+    Timing& t; int k; hipStream_t s;
+    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_) { if (t.on) t.begin(k, s); }
+    ~ScopedTimer() { if (t.on) t.end(k, s); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// context base
+// ---------------------------------------------------------------------------------------------------------
+class Context {
+public:
+    smo_config cfg{};
+    hipStream_t stream = nullptr;
+    DevPool pool;
+    Timing timing;
+    bool have_forward = false;
+    int n_comp = 1;
+    size_t vec_len = 0;          // doubles per component per batch member
+    size_t stack_bytes = 0;
+    size_t snapshot_doubles = 0;
+
+    virtual ~Context();
+    virtual int init() = 0;
+    virtual int forward_dev(const double* const* X, double* J_host) = 0;
+    virtual int adjoint_dev(const double* const* X, int adjoint_type, double* const* grad) = 0;
+    virtual int inner_dev(const double* x, const double* y, double* out_host) = 0;
+    virtual int snapshot_read(int b, int index, double* out) = 0;
+
+    // host-buffer variants: stage through context-owned device vectors
+    int forward_host(const double* const* X, double* J);
+    int adjoint_host(const double* const* X, int adjoint_type, double* const* grad);
+    int inner_host(const double* x, const double* y, double* out);
+
+protected:
+    int base_init();             // device selection, stream, staging buffers (needs n_comp / vec_len set)
+    double* stage_x[2] = {nullptr, nullptr};
+    double* stage_g[2] = {nullptr, nullptr};
+};
+
+Context* make_sh23(const smo_config& cfg);
+Context* make_shb23(const smo_config& cfg);
+Context* make_kdyn(const smo_config& cfg);
+
+}  // namespace smo

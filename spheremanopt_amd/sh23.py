@@ -1,0 +1,112 @@
+"""1-D periodic Swift-Hohenberg 2-3 — the reference's callbacks, backed by the HIP kernels of csrc/sh23.hip.
+
+Same names / positional signatures as Example_Problems/Periodic_Domain(Fourier)/Swift_Hohenberg/FWD_Solve_SH23.py:
+
+    FWD_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filename=None, Adjoint_type="Discrete")   :409
+    ADJ_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filename=None, Adjoint_type="Discrete")   :598
+    Inner_Prod(x, y, domain, rand_arg=None)                                                                        :158
+    Generate_IC(E_0, Npts, X)  -> (domain, X_0)                                                                    :174
+    GEN_BUFFER(domain, N_SUB_ITERS, Npts)  -> {'A_fwd': handle}                                                    :238
+
+so the reference's driver lines work unchanged:
+
+    args_IP = (domain, None); args_f = [domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, None, Adjoint_type]
+    Optimise_On_Multi_Sphere([X_0], [E_0], FWD_Solve_IVP_Lin, ADJ_Solve_IVP_Lin, Inner_Prod, args_f, args_IP, ...)
+
+The ``domain`` slot carries a :class:`SH23Domain` (geometry + cache of device contexts) instead of a Dedalus domain;
+``X_FWD_DICT['A_fwd']`` is a handle to the HBM-resident snapshot stack instead of a NumPy array.
+"""
+import numpy as np
+
+from . import _capi
+
+A_PARAM = -0.3       # FWD_Solve_SH23.py:309
+
+
+class SnapshotStack:
+    """Handle to the device-resident coefficient snapshots ('A_fwd' of GEN_BUFFER): ``stack[:, i]`` reads snapshot i."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.ctx = None
+
+    def __getitem__(self, key):
+        if self.ctx is None:
+            raise RuntimeError("snapshot stack is empty: run FWD_Solve_IVP_Lin first")
+        rows, idx = key
+        n = self.shape[1]
+        idx = idx + n if idx < 0 else idx
+        c = self.ctx.snapshot(idx).view(np.complex128)
+        return c[rows]
+
+
+class SH23Domain:
+    """Geometry of the periodic box + owner of the device contexts (one per (dt, N_ITERS, batch))."""
+
+    def __init__(self, Npts=256, X=(0., 12. * np.pi), dealias=2, device=0):
+        self.Npts, self.interval, self.dealias, self.device = int(Npts), (float(X[0]), float(X[1])), dealias, device
+        self.G = int(dealias * Npts)
+        self.Nc = (self.Npts - 1) // 2 + 1
+        self.hypervolume = self.interval[1] - self.interval[0]
+        self._ctx = {}
+
+    def grid(self):
+        return self.interval[0] + self.hypervolume * np.arange(self.G) / self.G
+
+    def context(self, dt, N_ITERS, batch=1):
+        key = (float(dt), int(N_ITERS), int(batch))
+        if key not in self._ctx:
+            self._ctx[key] = _capi.Context(_capi.SMO_SH23, self.Npts, self.interval, dt, N_ITERS, A_PARAM, batch=batch,
+                                           device=self.device)
+        return self._ctx[key]
+
+    def any_context(self):
+        if not self._ctx:
+            self.context(0.1, 1)
+        return next(iter(self._ctx.values()))
+
+
+def Generate_IC(E_0=1.0, Npts=256, X=(0., 12. * np.pi), seed=42, device=0):
+    """Domain + band-limited random initial condition with <X,X> = E_0 (synthetic-input recipe of SURVEY.md 8d:
+    seeded standard-normal noise on the scale-2 grid, modes with index fraction > 1/2 removed — the reference's
+    ``filter_field`` — then normalised; the reference's extra Dedalus smoothing run, FWD_Solve_SH23.py:228, is not part
+    of the hot path)."""
+    dom = SH23Domain(Npts, X, device=device)
+    G, Nc = dom.G, dom.Nc
+    noise = np.random.RandomState(seed).standard_normal(G)
+    c = np.fft.rfft(noise) / G
+    keep = np.zeros(G // 2 + 1, dtype=bool)
+    keep[:Nc] = np.linspace(0, 1, Nc, endpoint=False) <= 0.5
+    c[~keep] = 0
+    x = np.fft.irfft(c, n=G) * G
+    return dom, x * np.sqrt(E_0 / np.mean(x * x))
+
+
+def GEN_BUFFER(domain, N_SUB_ITERS, Npts=256):
+    return {'A_fwd': SnapshotStack((domain.Nc, N_SUB_ITERS + 1))}
+
+
+def _check_window(N_ITERS, N_SUB_ITERS):
+    if N_SUB_ITERS != N_ITERS:
+        raise NotImplementedError("windowed checkpointing (N_SUB_ITERS < N_ITERS) is not implemented (nor in the reference)")
+
+
+def FWD_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filename=None, Adjoint_type="Discrete"):
+    """-J(X) with J = dt * sum_{n=0}^{N} (1/L) int u_n^2 dx; fills the device snapshot stack."""
+    _check_window(N_ITERS, N_SUB_ITERS)
+    ctx = domain.context(dt, N_ITERS)
+    J = ctx.forward([X_k[0]])
+    X_FWD_DICT['A_fwd'].ctx = ctx
+    return J
+
+
+def ADJ_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filename=None, Adjoint_type="Discrete"):
+    """[dJ/dX] on the scale-2 grid; valid right after FWD_Solve_IVP_Lin at the same X_k (it replays that stack)."""
+    _check_window(N_ITERS, N_SUB_ITERS)
+    ctx = domain.context(dt, N_ITERS)
+    return ctx.adjoint(None, Adjoint_type)
+
+
+def Inner_Prod(x, y, domain, rand_arg=None):
+    """(1/L) int x y dx = mean over the scale-2 grid."""
+    return domain.any_context().inner(x, y)

@@ -1,0 +1,69 @@
+"""The C-ABI library: loads, exports every symbol include/smo.h declares, and refuses to run without a GPU
+(no CPU fallback).  No compute calls here — this file runs in the GPU-less build container."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from spheremanopt_amd import _capi
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "smo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(smo_[a-z_]+)\s*\(", hdr)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _capi.lib()
+
+
+def test_exports_match_header(L):
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_capi.EXPORTS) == names           # the Python binding covers exactly the header
+
+
+def test_version_and_error_strings(L):
+    assert b"libsmo" in L.smo_version()
+    assert isinstance(L.smo_last_error(), bytes)
+
+
+def test_bad_config_rejected(L):
+    h = C.c_void_p()
+    cfg = _capi.smo_config(_capi.SMO_SH23, 256, 0., 1., -1.0, 10, -0.3, 0, 1, 0, 0, 1)      # dt < 0
+    assert L.smo_create(C.byref(cfg), C.byref(h)) == 1 and not h.value
+    assert b"bad config" in L.smo_last_error()
+    cfg = _capi.smo_config(99, 256, 0., 1., 0.1, 10, -0.3, 0, 1, 0, 0, 1)                     # unknown kind
+    assert L.smo_create(C.byref(cfg), C.byref(h)) == 1
+    assert L.smo_forward(None, None, None) == 1                                               # null context
+
+
+def test_no_cpu_fallback(L):
+    """Without a HIP device the product path must fail loudly, not compute on the CPU."""
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.SmoError) as e:
+        _capi.Context(_capi.SMO_SH23, 64, (0., 1.), 0.1, 4, -0.3)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    from spheremanopt_amd import sh23
+    dom, X = sh23.Generate_IC(0.0725, Npts=64)
+    with pytest.raises(_capi.SmoError):
+        sh23.FWD_Solve_IVP_Lin([X], dom, 0.1, 4, 4, sh23.GEN_BUFFER(dom, 4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "spheremanopt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)

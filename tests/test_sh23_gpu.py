@@ -1,0 +1,117 @@
+"""SH23 HIP path (through the C-ABI) against the oracle and the committed fixtures.  Tolerance: north_star's
+1e-6 relative on J and grad J (observed ~1e-13)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from spheremanopt_amd import _capi, sh23
+from spheremanopt_amd.sphere_opt import Optimise_On_Multi_Sphere
+from spheremanopt_amd.test_grad import taylor_table
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def _oracle(Npts, dt, n):
+    from oracle.sh23 import SH23Oracle
+    return SH23Oracle(Npts, dt=dt, N_ITERS=n)
+
+
+@pytest.mark.parametrize("Npts,dt,n", [(16, 0.1, 3), (32, 0.05, 17), (64, 0.1, 40), (128, 0.1, 100), (1024, 0.02, 25)])
+@pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
+def test_forward_adjoint_vs_oracle(Npts, dt, n, adj):
+    dom, X = sh23.Generate_IC(0.0725, Npts=Npts, seed=42)
+    buf = sh23.GEN_BUFFER(dom, n)
+    args = [dom, dt, n, n, buf, None, adj]
+    J = sh23.FWD_Solve_IVP_Lin([X], *args)
+    g = sh23.ADJ_Solve_IVP_Lin([X], *args)
+    o = _oracle(Npts, dt, n)
+    Jo = o.forward([X]); go = o.adjoint([X], adj)
+    assert abs(J - Jo) <= RTOL * abs(Jo)
+    assert len(g) == 1 and g[0].shape == (2 * Npts,) and rel(g[0], go[0]) < RTOL
+    # snapshot stack: same contents, reference indexing A_fwd[:, i] incl. negative indices
+    for i in (0, 1, n // 2, -1, -2):
+        assert rel(buf['A_fwd'][:, i], o.stack[:, i]) < 1e-9
+    # inner product
+    assert abs(sh23.Inner_Prod(X, g[0], dom) - o.inner(X, go[0])) <= RTOL * abs(o.inner(X, go[0]))
+    assert abs(sh23.Inner_Prod(X, X, dom) - 0.0725) < 1e-12
+
+
+def test_config2_against_committed_oracle_output():
+    """BASELINE config 2: Npts=256, T=50, dt=0.1 (500 steps), seed-42 synthetic IC."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_sh23_c2.npz"))
+    dom, X = sh23.Generate_IC(0.0725, Npts=256, seed=42)
+    buf = sh23.GEN_BUFFER(dom, 500)
+    args = [dom, 0.1, 500, 500, buf, None, "Discrete"]
+    J = sh23.FWD_Solve_IVP_Lin([X], *args)
+    g = sh23.ADJ_Solve_IVP_Lin([X], *args)[0]
+    assert abs(J - gold["J"]) <= RTOL * abs(gold["J"])
+    assert rel(g, gold["grad"]) < RTOL
+    assert rel(buf['A_fwd'][:, -1], gold["stack_last"]) < 1e-9
+    args[-1] = "Continuous"
+    assert rel(sh23.ADJ_Solve_IVP_Lin([X], *args)[0], gold["grad_cont"]) < RTOL
+
+
+def test_taylor_remainder_on_device_path():
+    """The reference's own acceptance test (Adjoint_Gradient_Test) on the HIP path: second remainder ~ O(eps^2)."""
+    dom, X = sh23.Generate_IC(0.0725, Npts=256, seed=42)
+    _, dX = sh23.Generate_IC(0.0725, Npts=256, seed=7)
+    buf = sh23.GEN_BUFFER(dom, 500)
+    args_f = [dom, 0.1, 500, 500, buf, None, "Discrete"]
+    AA = taylor_table([X], [dX], sh23.FWD_Solve_IVP_Lin, sh23.ADJ_Solve_IVP_Lin, sh23.Inner_Prod, args_f, (dom, None),
+                      epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 5e-3), AA
+    assert np.all(np.abs(AA[3, :4] - 1.0) < 5e-2), AA
+
+
+def test_batched_problems_are_independent():
+    Npts, dt, n, B = 64, 0.1, 30, 5
+    dom = sh23.SH23Domain(Npts)
+    Xs = np.stack([sh23.Generate_IC(0.05 + 0.01 * b, Npts=Npts, seed=b)[1] for b in range(B)])
+    ctx = dom.context(dt, n, batch=B)
+    J = ctx.forward([Xs])
+    g = ctx.adjoint(None)[0].reshape(B, -1)
+    ip = ctx.inner(Xs, g)
+    for b in range(B):
+        o = _oracle(Npts, dt, n)
+        Jo = o.forward([Xs[b]]); go = o.adjoint([Xs[b]])[0]
+        assert abs(J[b] - Jo) <= RTOL * abs(Jo) and rel(g[b], go) < RTOL
+        assert abs(ip[b] - o.inner(Xs[b], go)) <= RTOL * abs(o.inner(Xs[b], go))
+        assert rel(ctx.snapshot(n, b).view(np.complex128), o.stack[:, n]) < 1e-9
+
+
+def test_adjoint_requires_forward_and_errors_are_loud():
+    ctx = _capi.Context(_capi.SMO_SH23, 64, (0., 12 * np.pi), 0.1, 5, -0.3)
+    with pytest.raises(_capi.SmoError) as e:
+        ctx.adjoint(None)
+    assert e.value.code == 4
+    with pytest.raises(ValueError):
+        ctx.forward([np.zeros(7)])
+    with pytest.raises(_capi.SmoError):
+        _capi.Context(_capi.SMO_SH23, 100, (0., 1.), 0.1, 5, -0.3)        # not a power of two
+
+
+def test_optimiser_runs_on_device_callbacks(in_tmp_cwd):
+    """Drop-in: the reference's driver call with the device-backed callbacks; J must decrease monotonically and the
+    iterate sequence must equal the one obtained with the oracle callbacks (bit-exact iteration/evaluation counts)."""
+    Npts, dt, n = 64, 0.1, 50
+    dom, X = sh23.Generate_IC(0.0725, Npts=Npts, seed=42)
+    buf = sh23.GEN_BUFFER(dom, n)
+    args_f = [dom, dt, n, n, buf, None, "Discrete"]
+    RES, FUN, Xopt = Optimise_On_Multi_Sphere([X.copy()], [0.0725], sh23.FWD_Solve_IVP_Lin, sh23.ADJ_Solve_IVP_Lin,
+                                              sh23.Inner_Prod, args_f, (dom, None), max_iters=6, alpha_k=np.pi,
+                                              LS='LS_wolfe', CG=True, verbose=False)
+    o = _oracle(Npts, dt, n)
+    RESo, FUNo, Xo = Optimise_On_Multi_Sphere([X.copy()], [0.0725], lambda X, *a: o.forward(X), lambda X, *a: o.adjoint(X),
+                                              lambda x, y, *a: o.inner(x, y), (), (), max_iters=6, alpha_k=np.pi,
+                                              LS='LS_wolfe', CG=True, verbose=False)
+    assert len(FUN) == len(FUNo) == 6
+    assert np.allclose(FUN, FUNo, rtol=1e-9) and np.allclose(RES, RESo, rtol=1e-6)
+    assert rel(Xopt[0], Xo[0]) < 1e-8
+    assert all(FUN[i + 1] >= FUN[i] for i in range(len(FUN) - 1))       # FUNCT stores -J_k = +J_phys: increasing
