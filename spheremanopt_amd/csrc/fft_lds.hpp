@@ -121,4 +121,82 @@ __device__ __forceinline__ void fft_batch(cplx* bufA, cplx* bufB, const cplx* tw
     MidStages<L, L / R0, R0, INV>::run(bufA, bufB, tw, NB, LD, tid, nthr, stN);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// In-place variant (one LDS buffer, register-staged): every stage loads its butterflies' inputs into registers,
+// synchronises, then stores.  Halves the LDS footprint (=> more workgroups per CU for the memory-bound 3-D passes).
+//   NB FFTs x L points, NT threads, CNT = ceil(NB*L/R / NT) butterflies per thread per stage (compile time).
+//   BFAST: consecutive lanes take consecutive FFTs b (strided passes: coalesced global access, use an odd LD);
+//          otherwise consecutive lanes take consecutive butterflies j of one FFT (contiguous passes).
+//   FIRST_LDS: ld0 reads the buffer itself (needs a barrier before the first store);
+//   LAST_LDS : stN writes the buffer itself (needs a barrier before the last store).
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, int PER, bool BFAST> __device__ __forceinline__ void split_index(int t, int& b, int& j) {
+    if (BFAST) { j = t / NB; b = t - j * NB; }
+    else       { b = t / PER; j = t - b * PER; }
+}
+
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class Load, class Store>
+__device__ __forceinline__ void inplace_stage(int tid, const cplx* __restrict__ tw, Load ld, Store st) {
+    constexpr int R = radix_of(N);
+    constexpr int M = N / R;
+    constexpr int PER = L / R;
+    constexpr int TOTAL = NB * PER;
+    constexpr int CNT = (TOTAL + NT - 1) / NT;
+    cplx v[CNT][R];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int t = tid + i * NT;
+        if (CNT * NT == TOTAL || t < TOTAL) {
+            int b, j;
+            split_index<NB, PER, BFAST>(t, b, j);
+            const int p = j / S, q = j - p * S;
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[i][k] = ld(b, q + S * (p + k * M));
+        }
+    }
+    if (PRE_BARRIER) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int t = tid + i * NT;
+        if (CNT * NT == TOTAL || t < TOTAL) {
+            int b, j;
+            split_index<NB, PER, BFAST>(t, b, j);
+            const int p = j / S, q = j - p * S;
+            Butterfly<R, INV>::run(v[i]);
+            st(b, q + S * (R * p), v[i][0]);
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                cplx o = v[i][k];
+                if (M > 1) o = twmul<INV>(o, tw[p * S * k]);
+                st(b, q + S * (R * p + k), o);
+            }
+        }
+    }
+}
+
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS> struct InplaceTail {
+    template <class StoreN>
+    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, const cplx* tw, StoreN stN) {
+        constexpr int R = radix_of(N);
+        auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
+        if constexpr (N / R == 1) {
+            inplace_stage<L, N, S, INV, NB, NT, BFAST, LAST_LDS>(tid, tw, ldL, stN);
+        } else {
+            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+            __syncthreads();
+            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN);
+        }
+    }
+};
+
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class Load0, class StoreN>
+__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, const cplx* tw, int tid, Load0 ld0, StoreN stN) {
+    constexpr int R0 = radix_of(L);
+    static_assert(L / R0 > 1, "transform needs at least two stages");
+    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+    __syncthreads();
+    InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN);
+}
+
 }  // namespace smo

@@ -1,5 +1,629 @@
-// KDYN (3-D kinematic dynamo) — placeholder until the kernels land.
-#include "smo_common.hpp"
+// KDYN — 3-D triply-periodic kinematic dynamo: CNAB1 forward solve of the induction equation and the discrete /
+// continuous adjoint sweep giving dJ/dB0 and dJ/dU.
+//
+// Replaces FWD_Solve_IVP_Lin / Compatib_Cond / ADJ_Solve_IVP_Lin / Inner_Prod_3 of
+// Example_Problems/Periodic_Domain(Fourier)/Kinematic_Dynamo/FWD_Solve_KDyn.py (:529-689, :696-764, :766-1004,
+// :173-181); recurrences: SURVEY.md Appendix A.2.
+//
+// Data layout in HBM (N = npts, a = N/2 kx modes, m = N-1 ky/kz modes, G = 3N/2 grid points per axis):
+//   coefficient fields  C [3][a][m][m]   complex128, kz fastest      (snapshot stack: [n][3][a][m][m])
+//   after the z pass    Tz[3][a][m][G]   complex128, z fastest
+//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slab-decomposed: [y-block][3][a_loc][Gy_loc][G])
+//   grid fields         U [3][G][G][G]   float64,    z fastest       (= the reference's flat X vectors)
+// One 3-D transform = three 1-D passes (z contiguous, y strided, x strided).  Every pass reads HBM in its first
+// Stockham stage (zero padding folded into the load) and writes HBM in its last (truncation folded into the store).
+// Fusions per time step:
+//   x pass  : c2r (two real lines per complex FFT) -> cross product with U (and B_f) on the grid -> r2c, one kernel
+//   z pass  : forward z transform -> i k x (.) -> Leray projection -> CNAB1 update -> next state written straight
+//             into the snapshot stack (the stack IS the state; no copy)
+//   curl    : omega = i k x G is formed while loading the z pass of the adjoint
+#include "fft_lds.hpp"
+
 namespace smo {
-Context* make_kdyn(const smo_config&) { set_error("KDYN device path not built yet"); return nullptr; }
+namespace {
+
+struct Geom {
+    int a;        // global number of kx modes (N/2)
+    int al;       // local number of kx modes (a / world)
+    int ix0;      // first global kx of this slab
+    int m;        // ky / kz modes (N-1)
+    int kmax;     // (N-1)/2
+    int G;        // grid points per axis (3N/2)
+    int Gyl;      // local y planes in grid space (G / world)
+    double Rm, dt;
+};
+
+__device__ __forceinline__ int wrap_pos(int pos, const Geom& g) {      // position in the padded length-G spectrum -> stored index, -1 in the gap
+    if (pos <= g.kmax) return pos;
+    if (pos >= g.G - g.kmax) return pos - (g.G - g.m);
+    return -1;
+}
+__device__ __forceinline__ double wavenumber(int idx, const Geom& g) { return (idx <= g.kmax) ? (double)idx : (double)(idx - g.m); }
+
+// (y index) -> offset of the (c, ixl, y) line of z values in the slab-exchange layout of Ty
+__device__ __forceinline__ size_t ty_line(int c, int ixl, int y, const Geom& g) {
+    const int blk = y / g.Gyl, yy = y - blk * g.Gyl;
+    return (((size_t)blk * 3 + c) * g.al + ixl) * ((size_t)g.Gyl * g.G) + (size_t)yy * g.G;
+}
+// x pass: offset of mode kx (global) of component c, flat local (y,z) index i
+__device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
+    const int blk = kx / g.al, kl = kx - blk * g.al;
+    return (((size_t)blk * 3 + c) * g.al + kl) * ((size_t)g.Gyl * g.G) + i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// z pass, inverse (coefficients -> Tz), rows contiguous.  NBT (ix,iy) row triples per workgroup.
+// ---------------------------------------------------------------------------------------------------------
+enum { ZI_PLAIN = 0, ZI_CURL = 1, ZI_SCALE = 2 };     // load the field | load i k x field | load dt*alpha(k)*field
+
+template <int L, int MODE, int NBT, int NT>
+__global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw_g,
+                                                   Geom g) {
+    constexpr int NB = 3 * NBT;
+    __shared__ cplx buf[NB * L];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const int nrt = g.al * g.m;
+    const int rt0 = blockIdx.x * NBT;
+    const size_t cs = (size_t)nrt * g.m;
+    auto ld0 = [&](int b, int pos) -> cplx {
+        const int tt = b / 3, c = b - 3 * tt, rt = rt0 + tt;
+        const int idx = wrap_pos(pos, g);
+        if (rt >= nrt || idx < 0) return mk(0, 0);
+        const size_t e = (size_t)rt * g.m + idx;
+        if (MODE == ZI_PLAIN) return in[c * cs + e];
+        const int ixl = rt / g.m, iy = rt - ixl * g.m;
+        const double k[3] = {(double)(g.ix0 + ixl), wavenumber(iy, g), wavenumber(idx, g)};
+        if (MODE == ZI_SCALE) {
+            const double s = g.dt * (1.0 / g.dt + 0.5 * (k[0] * k[0] + k[1] * k[1] + k[2] * k[2]) / g.Rm);
+            return s * in[c * cs + e];
+        }
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        cplx v1 = in[c1 * cs + e], v2 = in[c2 * cs + e];
+        return mul_i(mk(k[c1] * v2.re - k[c2] * v1.re, k[c1] * v2.im - k[c2] * v1.im));      // (i k x V)_c
+    };
+    auto stN = [&](int b, int pos, cplx v) {
+        const int tt = b / 3, c = b - 3 * tt, rt = rt0 + tt;
+        if (rt < nrt) out[((size_t)c * nrt + rt) * g.G + pos] = v;
+    };
+    fft_inplace<L, true, NB, NT, false, false, false>(buf, L, tw, tid, ld0, stN);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// z pass, forward (Tz -> coefficients), with the per-mode time-step fused in
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cnab_mode(const double k[3], double k2, double alpha, double beta, const cplx V0[3], const cplx F[3],
+                                          cplx V1[3]) {
+    if (k2 == 0.0) {                                    // algebraic rows under CNAB1: X1 = -X0
+        for (int c = 0; c < 3; ++c) V1[c] = mk(-V0[c].re, -V0[c].im);
+        return;
+    }
+    cplx r[3];
+    for (int c = 0; c < 3; ++c) r[c] = mk(beta * V0[c].re + F[c].re, beta * V0[c].im + F[c].im);
+    const double ik2 = 1.0 / k2;
+    const cplx kr = mk((k[0] * r[0].re + k[1] * r[1].re + k[2] * r[2].re) * ik2, (k[0] * r[0].im + k[1] * r[1].im + k[2] * r[2].im) * ik2);
+    const cplx kv = mk((k[0] * V0[0].re + k[1] * V0[1].re + k[2] * V0[2].re) * ik2,
+                       (k[0] * V0[0].im + k[1] * V0[1].im + k[2] * V0[2].im) * ik2);
+    for (int c = 0; c < 3; ++c)
+        V1[c] = mk((r[c].re - k[c] * kr.re) / alpha - k[c] * kv.re, (r[c].im - k[c] * kr.im) / alpha - k[c] * kv.im);
+}
+
+enum { ZF_PLAIN = 0, ZF_FWD_UPDATE = 1, ZF_ADJ_UPDATE = 2 };
+
+// NF = number of transformed fields (1: plain / forward update, 2: adjoint update: F1 spectra, then F2' spectra)
+template <int L, int MODE, int NBT, int NT>
+__global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA, const cplx* __restrict__ inB, cplx* out0, cplx* out1,
+                                                   const cplx* state0 /* may alias out0 */, const cplx* snap,
+                                                   const cplx* __restrict__ tw_g, Geom g, double scale, int integrated) {
+    constexpr int NF = (MODE == ZF_ADJ_UPDATE) ? 2 : 1;
+    constexpr int NB = 3 * NBT * NF;
+    __shared__ cplx buf[NB * L];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const int nrt = g.al * g.m;
+    const int rt0 = blockIdx.x * NBT;
+    const size_t cs = (size_t)nrt * g.m;
+    // b = (f * NBT + tt) * 3 + c
+    auto ld0 = [&](int b, int pos) -> cplx {
+        const int c = b % 3, ft = b / 3, f = ft / NBT, tt = ft - f * NBT, rt = rt0 + tt;
+        if (rt >= nrt) return mk(0, 0);
+        const cplx* src = (f == 0) ? inA : inB;
+        return src[((size_t)c * nrt + rt) * g.G + pos];
+    };
+    if (MODE == ZF_PLAIN) {
+        auto stN = [&](int b, int pos, cplx v) {
+            const int c = b % 3, tt = b / 3, rt = rt0 + tt;
+            const int idx = wrap_pos(pos, g);
+            if (rt < nrt && idx >= 0) out0[c * cs + (size_t)rt * g.m + idx] = scale * v;
+        };
+        fft_inplace<L, false, NB, NT, false, false, false>(buf, L, tw, tid, ld0, stN);
+        return;
+    }
+    fft_inplace<L, false, NB, NT, false, false, true>(buf, L, tw, tid, ld0, [&](int b, int pos, cplx v) { buf[b * L + pos] = v; });
+    __syncthreads();
+    // per-mode update: thread <-> (tt, iz), iz fastest
+    for (int t = tid; t < NBT * g.m; t += NT) {
+        const int tt = t / g.m, iz = t - tt * g.m, rt = rt0 + tt;
+        if (rt >= nrt) continue;
+        const int ixl = rt / g.m, iy = rt - ixl * g.m;
+        const int pos = (iz <= g.kmax) ? iz : iz + (g.G - g.m);
+        const double k[3] = {(double)(g.ix0 + ixl), wavenumber(iy, g), wavenumber(iz, g)};
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        const double D = k2 / g.Rm, alpha = 1.0 / g.dt + 0.5 * D, beta = 1.0 / g.dt - 0.5 * D;
+        const size_t e = (size_t)rt * g.m + iz;
+        cplx E[3], V0[3], V1[3];
+        for (int c = 0; c < 3; ++c) { E[c] = scale * buf[(tt * 3 + c) * L + pos]; V0[c] = state0[c * cs + e]; }
+        if (MODE == ZF_FWD_UPDATE) {
+            cplx F[3];                                  // N^ = i k x E^
+            for (int c = 0; c < 3; ++c) {
+                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                F[c] = mul_i(mk(k[c1] * E[c2].re - k[c2] * E[c1].re, k[c1] * E[c2].im - k[c2] * E[c1].im));
+            }
+            cnab_mode(k, k2, alpha, beta, V0, F, V1);
+            for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
+        } else {
+            // adjoint: G update (forcing F1 = F[(curl G) x U], minus 2 B_f if integrated), nu update (forcing -F[(curl G) x B_f])
+            cplx F2[3], nu0[3], nu1[3];
+            for (int c = 0; c < 3; ++c) {
+                F2[c] = scale * buf[((NBT + tt) * 3 + c) * L + pos];
+                nu0[c] = out1[c * cs + e];
+                if (integrated) { cplx bf = snap[c * cs + e]; E[c] = mk(E[c].re - 2.0 * bf.re, E[c].im - 2.0 * bf.im); }
+            }
+            cnab_mode(k, k2, alpha, beta, V0, E, V1);
+            if (k2 == 0.0) {
+                for (int c = 0; c < 3; ++c) nu1[c] = mk(-nu0[c].re, -nu0[c].im);
+            } else {
+                const double ik2 = 1.0 / k2;
+                const cplx kn = mk((k[0] * nu0[0].re + k[1] * nu0[1].re + k[2] * nu0[2].re) * ik2,
+                                   (k[0] * nu0[0].im + k[1] * nu0[1].im + k[2] * nu0[2].im) * ik2);
+                const cplx kf = mk((k[0] * F2[0].re + k[1] * F2[1].re + k[2] * F2[2].re) * ik2,
+                                   (k[0] * F2[0].im + k[1] * F2[1].im + k[2] * F2[2].im) * ik2);
+                for (int c = 0; c < 3; ++c)       // nu - 2 k (k.nu)/k2 + dt P(-F2')
+                    nu1[c] = mk(nu0[c].re - 2.0 * k[c] * kn.re - g.dt * (F2[c].re - k[c] * kf.re),
+                                nu0[c].im - 2.0 * k[c] * kn.im - g.dt * (F2[c].im - k[c] * kf.im));
+            }
+            for (int c = 0; c < 3; ++c) { out0[c * cs + e] = V1[c]; out1[c * cs + e] = nu1[c]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y pass (strided): Tz[3][al][m][G] <-> Ty (slab-exchange layout); ZT consecutive z per workgroup
+// ---------------------------------------------------------------------------------------------------------
+template <int L, bool INV, int ZT, int NT>
+__global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw_g, Geom g) {
+    constexpr int LD = L + 1;
+    __shared__ cplx buf[ZT * LD];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const int ntile = (g.G + ZT - 1) / ZT;
+    const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * al + ixl
+    const int c = o / g.al, ixl = o - c * g.al;
+    const cplx* tz = in;
+    if (INV) {
+        auto ld0 = [&](int b, int pos) -> cplx {
+            const int idx = wrap_pos(pos, g);
+            if (idx < 0 || z0 + b >= g.G) return mk(0, 0);
+            return tz[((size_t)o * g.m + idx) * g.G + z0 + b];
+        };
+        auto stN = [&](int b, int pos, cplx v) {
+            if (z0 + b < g.G) out[ty_line(c, ixl, pos, g) + z0 + b] = v;
+        };
+        fft_inplace<L, true, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
+    } else {
+        auto ld0 = [&](int b, int pos) -> cplx {
+            if (z0 + b >= g.G) return mk(0, 0);
+            return in[ty_line(c, ixl, pos, g) + z0 + b];
+        };
+        auto stN = [&](int b, int pos, cplx v) {
+            const int idx = wrap_pos(pos, g);
+            if (idx >= 0 && z0 + b < g.G) out[((size_t)o * g.m + idx) * g.G + z0 + b] = v;
+        };
+        fft_inplace<L, false, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x pass (strided, real <-> Hermitian half spectrum), two real lines per complex FFT, T flat (y,z) points per
+// workgroup.  Modes: spectrum -> grid; grid -> spectrum; fused  spectrum -> grid product(s) -> spectrum.
+// ---------------------------------------------------------------------------------------------------------
+enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
+
+template <int L, int MODE, int T, int NT>
+__global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut, const cplx* __restrict__ tw_g, Geom g) {
+    constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
+    constexpr int HP = T / 2;                       // line pairs
+    constexpr int NB = NF * 3 * HP;
+    constexpr int LD = L + 1;
+    __shared__ cplx buf[NB * LD];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const size_t plane = (size_t)g.Gyl * g.G;       // local (y,z) points
+    const size_t i0 = (size_t)blockIdx.x * T;
+    // b = (f*3 + c)*HP + p
+    auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
+
+    // -- load (spectrum, Hermitian extension) or (grid, two real lines) ------------------------------------------
+    auto ld_spec = [&](int b, int pos) -> cplx {
+        const int p = b % HP, fc = b / HP, c = fc % 3, f = fc / 3;
+        if (!line_ok(p)) return mk(0, 0);
+        const cplx* src = (f == 0) ? specA : specB;
+        int kx; bool cj;
+        if (pos < g.a) { kx = pos; cj = false; }
+        else if (pos > g.G - g.a) { kx = g.G - pos; cj = true; }
+        else return mk(0, 0);
+        const size_t off = tx_off(c, kx, i0 + 2 * p, g);
+        cplx X1 = src[off], X2 = src[off + 1];
+        if (kx == 0) return mk(X1.re, X2.re);                       // c2r ignores the imaginary part of kx = 0
+        if (cj) return mk(X1.re + X2.im, X2.re - X1.im);            // conj(X1) + i conj(X2)
+        return mk(X1.re - X2.im, X1.im + X2.re);                    // X1 + i X2
+    };
+    auto ld_grid = [&](int b, int pos) -> cplx {
+        const int p = b % HP, c = b / HP;
+        if (!line_ok(p)) return mk(0, 0);
+        const double* q = gridU + ((size_t)c * g.G + pos) * plane + i0 + 2 * p;
+        return mk(q[0], q[1]);
+    };
+    auto st_buf = [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; };
+
+    if (MODE == X_TO_GRID) {
+        fft_inplace<L, true, NB, NT, true, false, false>(buf, LD, tw, tid, ld_spec, [&](int b, int pos, cplx v) {
+            const int p = b % HP, c = b / HP;
+            if (line_ok(p)) {
+                double* q = gridOut + ((size_t)c * g.G + pos) * plane + i0 + 2 * p;
+                q[0] = v.re; q[1] = v.im;
+            }
+        });
+        return;
+    }
+    if (MODE == X_FROM_GRID) {
+        fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
+    } else {
+        fft_inplace<L, true, NB, NT, true, false, true>(buf, LD, tw, tid, ld_spec, st_buf);
+        __syncthreads();
+        // pointwise products on the grid; item = (x, p), p fastest
+        for (int t = tid; t < HP * L; t += NT) {
+            const int x = t / HP, p = t - x * HP;
+            if (!line_ok(p)) continue;
+            cplx A[3], U[3];                        // .re / .im = the two real lines of the pair
+            for (int c = 0; c < 3; ++c) {
+                A[c] = buf[(c * HP + p) * LD + x];
+                const double* q = gridU + ((size_t)c * g.G + x) * plane + i0 + 2 * p;
+                U[c] = mk(q[0], q[1]);
+            }
+            if (MODE == X_FUSED_FWD) {              // EMF = U x B
+                for (int c = 0; c < 3; ++c) {
+                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                    buf[(c * HP + p) * LD + x] = mk(U[c1].re * A[c2].re - U[c2].re * A[c1].re, U[c1].im * A[c2].im - U[c2].im * A[c1].im);
+                }
+            } else {                                // F1 = omega x U ;  F2' = omega x B_f
+                cplx Bf[3];
+                for (int c = 0; c < 3; ++c) Bf[c] = buf[((3 + c) * HP + p) * LD + x];
+                for (int c = 0; c < 3; ++c) {
+                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                    buf[(c * HP + p) * LD + x] = mk(A[c1].re * U[c2].re - A[c2].re * U[c1].re, A[c1].im * U[c2].im - A[c2].im * U[c1].im);
+                    buf[((3 + c) * HP + p) * LD + x] =
+                        mk(A[c1].re * Bf[c2].re - A[c2].re * Bf[c1].re, A[c1].im * Bf[c2].im - A[c2].im * Bf[c1].im);
+                }
+            }
+        }
+        __syncthreads();
+        fft_inplace<L, false, NB, NT, true, true, true>(buf, LD, tw, tid, [&](int b, int pos) { return buf[b * LD + pos]; }, st_buf);
+    }
+    __syncthreads();
+    // split the two real lines' spectra and store kx = 0..a-1; item = ((kx*NF*3 + fc)*HP + p), p fastest
+    for (int t = tid; t < g.a * NF * 3 * HP; t += NT) {
+        const int p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3);
+        if (!line_ok(p)) continue;
+        const int c = fc % 3, f = fc / 3;
+        const cplx Zk = buf[(fc * HP + p) * LD + kx];
+        const cplx Zm = conj(buf[(fc * HP + p) * LD + ((kx == 0) ? 0 : L - kx)]);
+        cplx* dst = ((f == 0) ? specA : specB) + tx_off(c, kx, i0 + 2 * p, g);
+        dst[0] = 0.5 * (Zk + Zm);
+        dst[1] = mul_mi(0.5 * (Zk - Zm));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small per-mode kernels
+// ---------------------------------------------------------------------------------------------------------
+// compatibility condition: G = P(-2 B_N) / (dt alpha)  (Final)  |  / alpha (Integrated);  continuous: G = -2 B_N
+__global__ void kd_terminal(const cplx* __restrict__ BN, cplx* __restrict__ Gh, cplx* __restrict__ nu, Geom g, int integrated, int continuous) {
+    const size_t nmode = (size_t)g.al * g.m * g.m;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nmode; e += (size_t)gridDim.x * blockDim.x) {
+        const int iz = e % g.m, iy = (e / g.m) % g.m, ixl = e / ((size_t)g.m * g.m);
+        const double k[3] = {(double)(g.ix0 + ixl), wavenumber(iy, g), wavenumber(iz, g)};
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        cplx r[3];
+        for (int c = 0; c < 3; ++c) { cplx b = BN[c * nmode + e]; r[c] = mk(-2.0 * b.re, -2.0 * b.im); nu[c * nmode + e] = mk(0, 0); }
+        if (!continuous) {
+            if (k2 == 0.0) { for (int c = 0; c < 3; ++c) r[c] = mk(0, 0); }
+            else {
+                const double alpha = 1.0 / g.dt + 0.5 * k2 / g.Rm, s = integrated ? alpha : g.dt * alpha, ik2 = 1.0 / k2;
+                const cplx kr = mk((k[0] * r[0].re + k[1] * r[1].re + k[2] * r[2].re) * ik2, (k[0] * r[0].im + k[1] * r[1].im + k[2] * r[2].im) * ik2);
+                for (int c = 0; c < 3; ++c) r[c] = mk((r[c].re - k[c] * kr.re) / s, (r[c].im - k[c] * kr.im) / s);
+            }
+        }
+        for (int c = 0; c < 3; ++c) Gh[c * nmode + e] = r[c];
+    }
+}
+
+// spectral energy  sum_k w |B^|^2  (w = 1 on the kx = 0 plane, 2 elsewhere) == grid mean of |B|^2 ; one partial per workgroup
+__global__ __launch_bounds__(256) void kd_energy(const cplx* __restrict__ Bh, double* __restrict__ partial, Geom g) {
+    __shared__ double red[4];
+    const size_t nmode = (size_t)g.al * g.m * g.m, plane = (size_t)g.m * g.m;
+    double acc = 0.0;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nmode; e += (size_t)gridDim.x * 256) {
+        const int ixl = e / plane;
+        const double w = (g.ix0 + ixl == 0) ? 1.0 : 2.0;
+        double s = 0.0;
+        for (int c = 0; c < 3; ++c) { cplx b = Bh[c * nmode + e]; s += b.re * b.re + b.im * b.im; }
+        acc += w * s;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kd_dot(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ partial, size_t n) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const size_t n2 = n / 2;
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        double2 a = x2[i], b = y2[i];
+        acc += a.x * b.x + a.y * b.y;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) acc += x[n - 1] * y[n - 1];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NPART = 1024;         // workgroups (= partial sums) of the reduction kernels
+
+class KDyn : public Context {
+public:
+    explicit KDyn(const smo_config& c) { cfg = c; }
+    Geom g{};
+    size_t nmode = 0, n_tz = 0, n_ty = 0, n_grid = 0;
+    cplx *d_stack = nullptr, *d_tzA = nullptr, *d_tzB = nullptr, *d_tyA = nullptr, *d_tyB = nullptr, *d_G = nullptr, *d_nu = nullptr;
+    cplx* d_tw = nullptr;
+    double *d_U = nullptr, *d_part = nullptr;
+    std::vector<double> h_part;
+    int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1;
+
+    cplx* snap(int n) { return d_stack + (size_t)n * 3 * nmode; }
+
+    int init() override {
+        const int N = cfg.npts;
+        if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
+        if (cfg.world != 1) { set_error("KDYN: the in-library path is single-GPU; the slab-decomposed path is driven by the host layer"); return SMO_ERR_UNSUPPORTED; }
+        if (N % 2 != 0 || !(N == 8 || N == 16 || N == 32 || N == 64 || N == 128 || N == 256)) {
+            set_error("KDYN: npts must be one of 8,16,32,64,128,256 (got %d)", N);
+            return SMO_ERR_UNSUPPORTED;
+        }
+        g.a = N / 2; g.al = g.a; g.ix0 = 0; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gyl = g.G;
+        g.Rm = cfg.param; g.dt = cfg.dt;
+        nmode = (size_t)g.al * g.m * g.m;
+        n_tz = (size_t)3 * g.al * g.m * g.G;
+        n_ty = (size_t)3 * g.al * g.G * g.G;
+        n_grid = (size_t)3 * g.G * g.Gyl * g.G;
+        n_comp = 2;
+        vec_len = n_grid;
+        snapshot_doubles = 2 * 3 * nmode;
+        stack_bytes = (size_t)(cfg.n_iters + 1) * 3 * nmode * sizeof(cplx);
+        SMO_TRY(base_init());
+        SMO_TRY(pool.upload(&d_tw, twiddles(g.G), stream));
+        SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nmode));
+        SMO_TRY(pool.alloc(&d_tzA, n_tz));
+        SMO_TRY(pool.alloc(&d_tzB, n_tz));
+        SMO_TRY(pool.alloc(&d_tyA, n_ty));
+        SMO_TRY(pool.alloc(&d_tyB, n_ty));
+        SMO_TRY(pool.alloc(&d_G, 3 * nmode));
+        SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
+        SMO_TRY(pool.alloc(&d_U, n_grid));
+        SMO_TRY(pool.alloc(&d_part, (size_t)NPART));
+        h_part.resize(NPART);
+        // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component)
+        const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.al * (double)g.G * g.G, S3 = 8.0 * (double)g.G * g.Gyl * g.G;
+        k_zi = timing.add_class("kd_z_inverse", 3 * (S0 + S1));
+        k_zic = timing.add_class("kd_z_inverse<curl>", 3 * (S0 + S1));
+        k_yi = timing.add_class("kd_y_pass<inv>", 3 * (S1 + S2));
+        k_yf = timing.add_class("kd_y_pass<fwd>", 3 * (S1 + S2));
+        k_xf = timing.add_class("kd_x_pass<fused_fwd>", 3 * (2 * (S2 + S3) + 3 * S3));           // 3 c2r + 3 r2c passes + pointwise (read B,U write EMF)
+        k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3));           // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2)
+        k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0);         // 3 z passes + step (read B,N; write B, snapshot)
+        k_zfa = timing.add_class("kd_z_forward<adj_update>", 6 * (S1 + S0) + 24 * S0);
+        k_misc = timing.add_class("kd_misc(setup/terminal/energy/grid io)", 0);
+        return SMO_OK;
+    }
+
+    // ---- launch helpers -----------------------------------------------------------------------------------------
+    template <class F> int with_L(F f) {
+        switch (g.G) {
+            case 12: return f(std::integral_constant<int, 12>());
+            case 24: return f(std::integral_constant<int, 24>());
+            case 48: return f(std::integral_constant<int, 48>());
+            case 96: return f(std::integral_constant<int, 96>());
+            case 192: return f(std::integral_constant<int, 192>());
+            case 384: return f(std::integral_constant<int, 384>());
+        }
+        set_error("KDYN: unsupported grid %d", g.G);
+        return SMO_ERR_UNSUPPORTED;
+    }
+    static constexpr int ZNBT = 4, ZNT = 192;        // z passes: 4 row triples (12 FFTs) per workgroup
+    static constexpr int ZA_NBT = 2, ZA_NT = 192;    // adjoint update: 2 row triples x 2 fields (12 FFTs)
+    static constexpr int YZT = 16, YNT = 256;        // y pass: 16 z columns per workgroup
+    static constexpr int XNT = 384;                  // x pass: 24 FFTs per workgroup (T = 16 forward, T = 8 adjoint)
+
+    int z_inverse(int mode, const cplx* in, cplx* out) {
+        const int nwg = (g.al * g.m + ZNBT - 1) / ZNBT;
+        return with_L([&](auto l) {
+            constexpr int L = decltype(l)::value;
+            ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
+            if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
+            else if (mode == ZI_CURL) hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
+            else hipLaunchKernelGGL((kd_z_inverse<L, ZI_SCALE, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
+            return SMO_OK;
+        });
+    }
+    int y_pass(bool inv, const cplx* in, cplx* out) {
+        const int nwg = 3 * g.al * ((g.G + YZT - 1) / YZT);
+        return with_L([&](auto l) {
+            constexpr int L = decltype(l)::value;
+            ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
+            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, in, out, d_tw, g);
+            else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, in, out, d_tw, g);
+            return SMO_OK;
+        });
+    }
+    int x_pass(int mode, cplx* specA, cplx* specB, const double* grid_in, double* grid_out) {
+        const size_t plane = (size_t)g.Gyl * g.G;
+        return with_L([&](auto l) {
+            constexpr int L = decltype(l)::value;
+            const int k = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
+            ScopedTimer t(timing, k, stream);
+            const int n16 = (int)((plane + 15) / 16), n8 = (int)((plane + 7) / 8);
+            switch (mode) {
+                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
+                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
+            }
+            return SMO_OK;
+        });
+    }
+    int z_forward(int mode, const cplx* inA, const cplx* inB, cplx* out0, cplx* out1, const cplx* state0, const cplx* snp) {
+        const double scale = 1.0 / ((double)g.G * g.G * g.G);
+        const int integ = cfg.cost == SMO_COST_INTEGRATED;
+        return with_L([&](auto l) {
+            constexpr int L = decltype(l)::value;
+            const int k = mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc);
+            ScopedTimer t(timing, k, stream);
+            if (mode == ZF_ADJ_UPDATE) {
+                const int nwg = (g.al * g.m + ZA_NBT - 1) / ZA_NBT;
+                hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, ZA_NBT, ZA_NT>), dim3(nwg), dim3(ZA_NT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+            } else {
+                const int nwg = (g.al * g.m + ZNBT - 1) / ZNBT;
+                if (mode == ZF_PLAIN) hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+                else hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+            }
+            return SMO_OK;
+        });
+    }
+    // grid vector (flat X layout) -> truncated coefficients
+    int grid_to_coeff(const double* X, cplx* out) {
+        SMO_TRY(x_pass(X_FROM_GRID, d_tyA, nullptr, X, nullptr));
+        SMO_TRY(y_pass(false, d_tyA, d_tzA));
+        return z_forward(ZF_PLAIN, d_tzA, nullptr, out, nullptr, nullptr, nullptr);
+    }
+    // coefficients -> grid vector; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
+    int coeff_to_grid(const cplx* C, double* X, bool scaled) {
+        SMO_TRY(z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, d_tzA));
+        SMO_TRY(y_pass(true, d_tzA, d_tyA));
+        return x_pass(X_TO_GRID, d_tyA, nullptr, nullptr, X);
+    }
+    int energy(const cplx* Bh, double* E) {
+        {
+            ScopedTimer t(timing, k_misc, stream);
+            hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, Bh, d_part, g);
+        }
+        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        double s = 0.0;
+        for (int i = 0; i < NPART; ++i) s += h_part[i];
+        *E = s;
+        return SMO_OK;
+    }
+
+    // ---- the three callbacks ---------------------------------------------------------------------------------------
+    int forward_dev(const double* const* X, double* J) override {
+        have_forward = false;
+        const int N = cfg.n_iters;
+        // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver)
+        SMO_TRY(grid_to_coeff(X[1], d_G));
+        SMO_TRY(coeff_to_grid(d_G, d_U, false));
+        SMO_TRY(grid_to_coeff(X[0], snap(0)));
+        double Jacc = 0.0, E = 0.0;
+        const bool integ = cfg.cost == SMO_COST_INTEGRATED;
+        for (int n = 0; n < N; ++n) {
+            if (integ) { SMO_TRY(energy(snap(n), &E)); Jacc += cfg.dt * E; }
+            SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA));
+            SMO_TRY(y_pass(true, d_tzA, d_tyA));
+            SMO_TRY(x_pass(X_FUSED_FWD, d_tyA, nullptr, d_U, nullptr));
+            SMO_TRY(y_pass(false, d_tyA, d_tzA));
+            SMO_TRY(z_forward(ZF_FWD_UPDATE, d_tzA, nullptr, snap(n + 1), nullptr, snap(n), nullptr));
+        }
+        SMO_TRY(energy(snap(N), &E));
+        Jacc = integ ? Jacc + cfg.dt * E : E;
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        *J = -Jacc;
+        have_forward = true;
+        return SMO_OK;
+    }
+
+    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        const int N = cfg.n_iters;
+        const bool cont = adjoint_type == SMO_ADJ_CONTINUOUS;
+        const int integ = cfg.cost == SMO_COST_INTEGRATED;
+        {
+            ScopedTimer t(timing, k_misc, stream);
+            hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(N), d_G, d_nu, g, integ, cont ? 1 : 0);
+        }
+        int idx = cont ? N : N - 1;
+        for (int it = 0; it < N; ++it, --idx) {
+            SMO_TRY(z_inverse(ZI_CURL, d_G, d_tzA));
+            SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
+            SMO_TRY(y_pass(true, d_tzA, d_tyA));
+            SMO_TRY(y_pass(true, d_tzB, d_tyB));
+            SMO_TRY(x_pass(X_FUSED_ADJ, d_tyA, d_tyB, d_U, nullptr));
+            SMO_TRY(y_pass(false, d_tyA, d_tzA));
+            SMO_TRY(y_pass(false, d_tyB, d_tzB));
+            SMO_TRY(z_forward(ZF_ADJ_UPDATE, d_tzA, d_tzB, d_G, d_nu, d_G, snap(idx)));
+        }
+        SMO_TRY(coeff_to_grid(d_G, grad[0], !cont));
+        SMO_TRY(coeff_to_grid(d_nu, grad[1], false));
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
+    int inner_dev(const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        double s = 0.0;
+        for (int i = 0; i < NPART; ++i) s += h_part[i];
+        *out = s / ((double)g.G * g.G * g.G);
+        return SMO_OK;
+    }
+
+    int snapshot_read(int, int index, double* out) override {
+        SMO_HIP(hipMemcpyAsync(out, snap(index), 3 * nmode * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+};
+
+}  // namespace
+
+Context* make_kdyn(const smo_config& cfg) { return new KDyn(cfg); }
+
 }  // namespace smo

