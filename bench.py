@@ -84,6 +84,68 @@ def bench_sh23(a, torch, rank, world):
     return steps, warm, el, a.batch, roof, cfg, cpu
 
 
+def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
+    """Oracle timed on a bounded sample: `sample_steps` forward + adjoint steps at the full grid, scaled to n_iters."""
+    from oracle.kdyn import KDynOracle
+    o = KDynOracle(N, Rm=Rm, dt=dt, N_ITERS=sample_steps, workers=workers)
+    t0 = time.perf_counter()
+    o.forward([B, U]); o.adjoint([B, U])
+    el = time.perf_counter() - t0
+    per_step = el / sample_steps          # includes the one-off transforms of X and the final gradient transforms
+    return {"value": 1.0 / (per_step * n_iters), "unit": "gradient evals/s", "cores": workers, "kind": "port",
+            "sample": "%d of %d forward+adjoint time steps at the full %d^3 grid (NumPy/pocketfft restatement of the Dedalus "
+                      "path, %d thread(s)), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers, el)}
+
+
+def bench_kdyn(a, torch, rank, world):
+    from spheremanopt_amd import kdyn
+    N = a.npts or 128
+    Rm, dt = 1.0, 1e-3
+    n_iters = a.iters or 1000
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup is not None else 1
+    dom, B, U = kdyn.Generate_IC(N, U_Noise=True, device=torch.cuda.current_device())
+    ctx = dom.context(Rm, dt, n_iters, "Final")
+    Bd, Ud = torch.from_numpy(B).cuda(), torch.from_numpy(U).cuda()
+    gB, gU = torch.empty_like(Bd), torch.empty_like(Ud)
+    for _ in range(warm):
+        ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
+    ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        J = ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tim = ctx.timing()
+    tot_ms = sum(t["total_ms"] for t in tim)
+    dom_k = max(tim, key=lambda t: t["total_ms"])
+    avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
+            "kernel_time_share": dom_k["total_ms"] / tot_ms,
+            "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1),
+                             "GBps": (t["bytes_per_launch"] / (t["total_ms"] / max(t["launches"], 1) * 1e-3) / 1e9) if t["launches"] else 0.0}
+                            for t in tim],
+            "whole_gradient_algorithmic_TB": None}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    # whole-job figure with SURVEY 8d's per-step bytes: fwd 6T+9S3+12S0, adj 12T+15S3+24S0
+    a_, m_, G_ = N // 2, N - 1, 3 * N // 2
+    S0, S1, S2, S3 = 16. * a_ * m_ * m_, 16. * a_ * m_ * G_, 16. * a_ * G_ * G_, 8. * G_ ** 3
+    T = S0 + 2 * S1 + 2 * S2 + S3
+    per_grad = n_iters * ((6 * T + 9 * S3 + 12 * S0) + (12 * T + 15 * S3 + 24 * S0))
+    roof["whole_gradient_algorithmic_TB"] = per_grad / 1e12
+    roof["whole_gradient_GBps"] = per_grad / (el / steps) / 1e9
+    cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
+                       % (N, Rm, dt * n_iters, dt),
+           "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "J": J, "parallelism": "1 GPU"}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1)
+        cfg["cpu_all_cores"] = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, os.cpu_count() or 1)
+    return steps, warm, el, 1, roof, cfg, cpu
+
+
 def main():
     a = parse()
     import torch
@@ -95,9 +157,11 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         torch.distributed.init_process_group("nccl")
-    wl = a.workload or "sh23"
+    wl = a.workload or "kdyn"
     if wl == "sh23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
+    elif wl == "kdyn":
+        steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
     else:
         raise SystemExit("workload %s not built yet" % wl)
     if world > 1:

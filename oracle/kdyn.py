@@ -175,6 +175,6 @@ def synthetic_field(G, seed, M0=1.0):
     V = np.stack([np.fft.rfftn(rs.standard_normal((G, G, G))) for _ in range(3)]) * keep
     V = V - K * ((K * V).sum(0) / k2)
     V[:, 0, 0, 0] = 0.
-    v = np.stack([np.fft.irfftn(V[i], s=(G, G, G)) for i in range(3)])
+    v = np.stack([np.fft.irfftn(V[i], s=(G, G, G), axes=(0, 1, 2)) for i in range(3)])
     v *= np.sqrt(M0 / np.mean((v * v).sum(0)))
     return v.reshape(-1)
