@@ -112,10 +112,14 @@ def bench_kdyn(a, torch, rank, world):
         ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
     ctx.timing_enable(True)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         J = ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     el = time.perf_counter() - t0
     tim = ctx.timing()
     tot_ms = sum(t["total_ms"] for t in tim)
@@ -138,7 +142,8 @@ def bench_kdyn(a, torch, rank, world):
     roof["whole_gradient_GBps"] = per_grad / (el / steps) / 1e9
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
-           "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "J": J, "parallelism": "1 GPU"}
+           "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "J": J,
+           "parallelism": "1 GPU" if world == 1 else "replicas only (x%d independent gradients)" % world}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1)
