@@ -129,18 +129,3 @@ def Inner_Prod_3(x, y, domain, random_arg=None):
     """Sum over the three components of the grid mean of x*y."""
     return domain.any_context().inner(x, y)
 
-
-def smoke_check():
-    """Tiny gradient on cuda:0 vs the oracle (called by __graft_entry__.smoke)."""
-    from oracle.kdyn import KDynOracle
-    dom, B, U = Generate_IC(16, U_Noise=True)
-    n, dt = 5, 1e-2
-    buf = GEN_BUFFER(16, dom, n)
-    args = [dom, 1., dt, n, n, buf, "Final", "Discrete"]
-    J = FWD_Solve_IVP_Lin([B, U], *args)
-    gB, gU = ADJ_Solve_IVP_Lin([B, U], *args)
-    o = KDynOracle(16, Rm=1., dt=dt, N_ITERS=n)
-    Jo = o.forward([B, U]); goB, goU = o.adjoint([B, U])
-    eB = np.linalg.norm(gB - goB) / np.linalg.norm(goB); eU = np.linalg.norm(gU - goU) / np.linalg.norm(goU)
-    assert abs(J - Jo) <= 1e-6 * abs(Jo) and eB < 1e-6 and eU < 1e-6, (J, Jo, eB, eU)
-    print("smoke kdyn: J=%.12e (oracle %.12e)  grad rel err B %.2e U %.2e" % (J, Jo, eB, eU))
