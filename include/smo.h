@@ -94,6 +94,10 @@ int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double
 int smo_snapshot_len(const smo_ctx* ctx, size_t* ndoubles);
 int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out);
 
+/* The reference's standalone Chebyshev maps (SHB23 only; FWD_Solve_SHB23.py:36-67), host buffers of npts doubles:
+ * which = 0 transform (grid->T coefficients), 1 transformInverse, 2 transformAdjoint, 3 transformInverseAdjoint. */
+int smo_transform(smo_ctx* ctx, int which, const double* in, double* out);
+
 /* HIP-event timing of the kernels launched by the context (measured on the context's stream).
  * smo_timing_enable(ctx, 1) resets the accumulators; smo_timing_get returns, for kernel class `k`
  * (0 <= k < smo_timing_classes), its name, number of launches, total milliseconds and the ALGORITHMIC bytes

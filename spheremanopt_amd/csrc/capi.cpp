@@ -148,6 +148,13 @@ int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out) {
     return ctx->impl->snapshot_read(b, index, out);
 }
 
+int smo_transform(smo_ctx* ctx, int which, const double* in, double* out) {
+    CHECK_CTX(ctx);
+    if (!in || !out || which < 0 || which > 3) { smo::set_error("smo_transform: bad argument"); return SMO_ERR_ARG; }
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->transform_host(which, in, out);
+}
+
 int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
     ctx->impl->timing.reset();

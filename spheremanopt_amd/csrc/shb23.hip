@@ -1,5 +1,475 @@
-// SHB23 (1-D Chebyshev Swift-Hohenberg) — placeholder until the kernels land.
-#include "smo_common.hpp"
+// SHB23 — 1-D Swift-Hohenberg on z in [z0,z1] with Chebyshev-tau boundary conditions, "Discrete" path:
+// hand-stepped SBDF1 forward solve and its exact transpose (discrete adjoint).
+//
+// Replaces FWD_Solve_IVP_Discrete / ADJ_Solve_IVP_Discrete / Inner_Prod_Discrete and the transform helpers of
+// Example_Problems/Bounded_Domain(Cheby)/Swift_Hohenberg_Bounded/FWD_Solve_SHB23.py (:525-678, :796-920, :189-193,
+// :36-81); recurrences: SURVEY.md Appendix A.3.
+//
+// The reference solves, every step, a 4N x 4N Chebyshev-tau system through Dedalus' pencil LU.  Only the block
+// "rhs of the first equation -> u" matters: an N x N operator S that depends on (N, dt, a, interval) alone.  It is built
+// ONCE per context on the host (banded + 4 boundary rows, sparse-aware LU with partial pivoting) and kept in HBM/L2
+// (2 MB at N = 512); a step is then   c <- S (Z T[2g^2 - g^3] + c/dt),  g = T^-1 c   with
+//   T, T^-1, T^T, T^-T  = DCT-II / DCT-III of length N through one complex Stockham FFT of length N/2 in LDS
+//   S r, S^T p          = column-streaming GEMV over the 1024 threads of the (single) workgroup.
+// One problem = one workgroup running the whole time loop (latency-bound config); `batch` problems = `batch` workgroups
+// sharing S through L2.
+#include <algorithm>
+
+#include "fft_lds.hpp"
+
 namespace smo {
-Context* make_shb23(const smo_config&) { set_error("SHB23 device path not built yet"); return nullptr; }
+namespace {
+
+constexpr int NT = 1024;
+
+// ---------------------------------------------------------------------------------------------------------
+// host: tau operator
+// ---------------------------------------------------------------------------------------------------------
+// Unknown / equation numbering interleaved by Chebyshev mode (index 4*n + v) so the system is banded apart from the four
+// boundary rows.  Equations (T -> U conversion "Pre" applied, last row of each block replaced by a boundary row):
+//   e0: Pre[(1/dt + 1 - a) u + 2 uzz + D uzzz] = Pre rhs      bc: left(uz)   = 0
+//   e1: Pre[uz   - D u  ] = 0                                  bc: left(uzzz) = 0
+//   e2: Pre[uzz  - D uz ] = 0                                  bc: right(u)   = 0
+//   e3: Pre[uzzz - D uzz] = 0                                  bc: right(uzz) = 0
+// Pre[n][n] = 1 (n=0) | 1/2, Pre[n][n+2] = -1/2;  (Pre D)[n][n+1] = (n+1)/stretch  (d/dx T_n = n U_{n-1}).
+static int build_tau_operator(int N, double dt, double a, double z0, double z1, std::vector<double>& S) {
+    const int n4 = 4 * N;
+    const double stretch = 0.5 * (z1 - z0), c0 = 1.0 / dt + 1.0 - a;
+    std::vector<double> A((size_t)n4 * n4, 0.0), B((size_t)n4 * N, 0.0);
+    auto at = [&](int r, int c) -> double& { return A[(size_t)r * n4 + c]; };
+    auto pre_row = [&](int n, auto&& f) {            // f(col_mode, weight) over the non-zeros of row n of Pre
+        f(n, n == 0 ? 1.0 : 0.5);
+        if (n + 2 < N) f(n + 2, -0.5);
+    };
+    for (int n = 0; n < N - 1; ++n) {                 // rows 0..N-2 of every block; row N-1 holds the boundary condition
+        pre_row(n, [&](int j, double w) {
+            at(4 * n + 0, 4 * j + 0) += w * c0;  at(4 * n + 0, 4 * j + 2) += w * 2.0;
+            at(4 * n + 1, 4 * j + 1) += w;       at(4 * n + 2, 4 * j + 2) += w;     at(4 * n + 3, 4 * j + 3) += w;
+            B[(size_t)(4 * n + 0) * N + j] += w;                                      // Pre * rhs
+        });
+        const double d = (n + 1) / stretch;            // (Pre D)[n][n+1]
+        at(4 * n + 0, 4 * (n + 1) + 3) += d;
+        at(4 * n + 1, 4 * (n + 1) + 0) -= d;
+        at(4 * n + 2, 4 * (n + 1) + 1) -= d;
+        at(4 * n + 3, 4 * (n + 1) + 2) -= d;
+    }
+    const int bc_var[4] = {1, 3, 0, 2};
+    const bool bc_left[4] = {true, true, false, false};
+    for (int e = 0; e < 4; ++e)
+        for (int j = 0; j < N; ++j) at(4 * (N - 1) + e, 4 * j + bc_var[e]) = (bc_left[e] && (j & 1)) ? -1.0 : 1.0;
+
+    // LU with partial pivoting that skips structural zeros (rows keep a "last non-zero column" bound)
+    std::vector<int> hi(n4);
+    for (int r = 0; r < n4; ++r) {
+        int h = 0;
+        for (int c = n4 - 1; c >= 0; --c) if (at(r, c) != 0.0) { h = c; break; }
+        hi[r] = h;
+    }
+    for (int k = 0; k < n4; ++k) {
+        int p = -1; double best = 0.0;
+        for (int r = k; r < n4; ++r) { const double v = std::fabs(at(r, k)); if (v > best) { best = v; p = r; } }
+        if (p < 0) { set_error("SHB23: tau matrix is singular at column %d", k); return SMO_ERR_ARG; }
+        if (p != k) {
+            std::swap_ranges(&at(k, 0), &at(k, 0) + n4, &at(p, 0));
+            std::swap_ranges(&B[(size_t)k * N], &B[(size_t)k * N] + N, &B[(size_t)p * N]);
+            std::swap(hi[k], hi[p]);
+        }
+        const double piv = at(k, k);
+        const int hk = hi[k];
+        for (int r = k + 1; r < n4; ++r) {
+            const double f = at(r, k);
+            if (f == 0.0) continue;
+            const double l = f / piv;
+            at(r, k) = 0.0;
+            double* ar = &at(r, 0); const double* ak = &at(k, 0);
+            for (int c = k + 1; c <= hk; ++c) ar[c] -= l * ak[c];
+            double* br = &B[(size_t)r * N]; const double* bk = &B[(size_t)k * N];
+            for (int j = 0; j < N; ++j) br[j] -= l * bk[j];
+            hi[r] = std::max(hi[r], hk);
+        }
+    }
+    for (int k = n4 - 1; k >= 0; --k) {               // back substitution, all N right-hand sides at once
+        double* bk = &B[(size_t)k * N];
+        for (int c = k + 1; c <= hi[k]; ++c) {
+            const double u = at(k, c);
+            if (u == 0.0) continue;
+            const double* bc = &B[(size_t)c * N];
+            for (int j = 0; j < N; ++j) bk[j] -= u * bc[j];
+        }
+        const double inv = 1.0 / at(k, k);
+        for (int j = 0; j < N; ++j) bk[j] *= inv;
+    }
+    S.assign((size_t)N * N, 0.0);
+    for (int n = 0; n < N; ++n) std::copy(&B[(size_t)(4 * n) * N], &B[(size_t)(4 * n) * N] + N, &S[(size_t)n * N]);
+    return SMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device: DCT-II / DCT-III (scipy's unnormalised conventions) of length N = 2*NH on an LDS vector
+// ---------------------------------------------------------------------------------------------------------
+template <int NH> struct DctWork {
+    cplx P[NH], bufA[NH], bufB[NH], tw[NH];     // packed sequence, FFT ping-pong, exp(-2 pi i k / NH)
+    cplx twN[NH];                               // exp(-2 pi i k / N)
+    cplx tw4[NH + 1];                           // exp(-i pi k / (2N))
+};
+
+// y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N))         (x, y: LDS, may alias)
+template <int NH> __device__ void dct2(DctWork<NH>& w, const double* x, double* y, int tid) {
+    constexpr int N = 2 * NH;
+    for (int n = tid; n < NH; n += NT) {             // Makhoul permutation, two reals per complex
+        const double e = (2 * n < NH) ? x[4 * n] : x[2 * N - 1 - 4 * n];
+        const double o = (2 * n + 1 < NH) ? x[4 * n + 2] : x[2 * N - 3 - 4 * n];
+        w.P[n] = mk(e, o);
+    }
+    __syncthreads();
+    fft_batch<NH, false>(w.bufA, w.bufB, w.tw, 1, NH, tid, NT, [&](int, int pos) { return w.P[pos]; },
+                         [&](int, int pos, cplx v) { w.P[pos] = v; });
+    __syncthreads();
+    for (int k = tid; k <= NH; k += NT) {
+        if (k == 0) { const cplx Z0 = w.P[0]; y[0] = 2.0 * (Z0.re + Z0.im); y[NH] = 1.4142135623730951 * (Z0.re - Z0.im); }
+        else if (k < NH) {
+            const cplx Zk = w.P[k], Zm = conj(w.P[NH - k]);
+            const cplx V = 0.5 * (Zk + Zm) + mul_mi(0.5 * (Zk - Zm)) * w.twN[k];
+            const cplx t = V * w.tw4[k];
+            y[k] = 2.0 * t.re;
+            y[N - k] = -2.0 * t.im;
+        }
+    }
+    __syncthreads();
+}
+
+// y[n] = x[0] + 2 sum_{k>=1} x[k] cos(pi k (2n+1) / (2N))
+template <int NH> __device__ void dct3(DctWork<NH>& w, const double* x, double* y, int tid) {
+    constexpr int N = 2 * NH;
+    auto V = [&](int k) -> cplx {                    // half spectrum of the permuted sequence, k = 0..NH
+        if (k == 0) return mk(x[0], 0.0);
+        if (k == NH) return mk(1.4142135623730951 * x[NH], 0.0);
+        return mul_conj(mk(x[k], -x[N - k]), w.tw4[k]);
+    };
+    for (int k = tid; k < NH; k += NT) {
+        const cplx a = V(k), b = conj(V(NH - k));
+        w.P[k] = (a + b) + mul_i(mul_conj(a - b, w.twN[k]));
+    }
+    __syncthreads();
+    fft_batch<NH, true>(w.bufA, w.bufB, w.tw, 1, NH, tid, NT, [&](int, int pos) { return w.P[pos]; },
+                        [&](int, int pos, cplx v) { w.P[pos] = v; });
+    __syncthreads();
+    for (int m = tid; m < N; m += NT) {              // undo the permutation: y[2j] = v[j], y[2j+1] = v[N-1-j]
+        const int j = (m & 1) ? (N - 1 - (m >> 1)) : (m >> 1);
+        const cplx z = w.P[j >> 1];
+        y[m] = (j & 1) ? z.im : z.re;
+    }
+    __syncthreads();
+}
+
+// out[n] = sum_j M[j][n] v[j]   (M row j contiguous in n: coalesced 16-byte loads; v, out, part in LDS)
+__device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
+    const int npairs = N >> 1, ngrp = NT / npairs, cols = N / ngrp;
+    const int np = tid % npairs, jg = tid / npairs;
+    const double2* M2 = reinterpret_cast<const double2*>(M);
+    double a0 = 0.0, a1 = 0.0;
+    const int j0 = jg * cols;
+#pragma unroll 8
+    for (int j = j0; j < j0 + cols; ++j) {
+        const double2 m = M2[(size_t)j * npairs + np];
+        const double vj = v[j];
+        a0 += m.x * vj;
+        a1 += m.y * vj;
+    }
+    part[jg * N + 2 * np] = a0;
+    part[jg * N + 2 * np + 1] = a1;
+    __syncthreads();
+    for (int n = tid; n < N; n += NT) {
+        double s = 0.0;
+        for (int gidx = 0; gidx < ngrp; ++gidx) s += part[gidx * N + n];
+        out[n] = s;
+    }
+    __syncthreads();
+}
+
+template <int NH> struct ShbShared {
+    DctWork<NH> w;
+    double c[2 * NH], g[2 * NH], r[2 * NH], t[2 * NH], W[2 * NH];
+    double part[2 * NT];
+    double red[NT / 64];
+};
+
+template <int NH> __device__ void load_tables(ShbShared<NH>& s, const cplx* tw_g, const cplx* twN_g, const cplx* tw4_g, const double* W_g, int tid) {
+    for (int i = tid; i < NH; i += NT) { s.w.tw[i] = tw_g[i]; s.w.twN[i] = twN_g[i]; }
+    for (int i = tid; i <= NH; i += NT) s.w.tw4[i] = tw4_g[i];
+    for (int i = tid; i < 2 * NH; i += NT) s.W[i] = W_g[i];
+    __syncthreads();
+}
+
+// forward: J = -dt * sum_{n=0}^{N_ITERS} <g_n, g_n>_W ; stack[n] = g_n (grid states)
+template <int NH>
+__global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restrict__ X, double* __restrict__ stack, double* __restrict__ Jout,
+                                                         const double* __restrict__ ST, const double* __restrict__ W_g,
+                                                         const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
+                                                         const cplx* __restrict__ tw4_g, double dt, double inv_Lz, int n_iters) {
+    constexpr int N = 2 * NH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    const int tid = threadIdx.x;
+    const size_t prob = blockIdx.x;
+    X += prob * N;
+    stack += prob * (size_t)(n_iters + 1) * N;
+    load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
+    for (int i = tid; i < N; i += NT) s.t[i] = X[i];
+    __syncthreads();
+    // c = T X : dct2 / N, c[0] *= 1/2, odd modes * -1
+    dct2(s.w, s.t, s.c, tid);
+    for (int k = tid; k < N; k += NT) s.c[k] *= ((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N;
+    __syncthreads();
+    double acc = 0.0;
+    const double inv_dt = 1.0 / dt;
+    for (int it = 0; it <= n_iters; ++it) {
+        // g = T^-1 c : dct3 of (c0, s_k c_k / 2)
+        for (int k = tid; k < N; k += NT) s.t[k] = (k == 0) ? s.c[0] : ((k & 1) ? -0.5 : 0.5) * s.c[k];
+        __syncthreads();
+        dct3(s.w, s.t, s.g, tid);
+        for (int i = tid; i < N; i += NT) {
+            const double gi = s.g[i];
+            stack[(size_t)it * N + i] = gi;
+            acc += s.W[i] * gi * gi;
+            s.t[i] = gi * gi * (2.0 - gi);            // 2 g^2 - g^3
+        }
+        if (it == n_iters) break;
+        __syncthreads();
+        dct2(s.w, s.t, s.r, tid);                      // h = Z T[...]
+        for (int k = tid; k < N; k += NT) {
+            const double h = (k < NH) ? s.r[k] * (((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N) : 0.0;
+            s.r[k] = h + s.c[k] * inv_dt;
+        }
+        __syncthreads();
+        gemv_cols(ST, s.r, s.c, s.part, N, tid);       // c = S r
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((tid & 63) == 0) s.red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < NT / 64; ++i) tot += s.red[i];
+        Jout[prob] = -dt * inv_Lz * tot;
+    }
+}
+
+// adjoint: p = 2 dt T^-T(W g_N); repeat N_ITERS times: r = S^T p; p = r/dt + T^-T[(4b - 3b^2) T^T r + 2 dt W b]; grad = -T^T p / W
+template <int NH>
+__global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restrict__ stack, double* __restrict__ grad, const double* __restrict__ Sm,
+                                                         const double* __restrict__ W_g, const cplx* __restrict__ tw_g,
+                                                         const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters) {
+    constexpr int N = 2 * NH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    const int tid = threadIdx.x;
+    const size_t prob = blockIdx.x;
+    stack += prob * (size_t)(n_iters + 1) * N;
+    grad += prob * N;
+    load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
+    const double inv_dt = 1.0 / dt;
+    auto tinv_adj = [&](const double* in, double* out) {           // T^-T x = 1/2 s o DCT2(x), s_0 = 1
+        dct2(s.w, in, out, tid);
+        for (int k = tid; k < N; k += NT) out[k] *= (k & 1) ? -0.5 : 0.5;
+        __syncthreads();
+    };
+    for (int i = tid; i < N; i += NT) s.t[i] = 2.0 * dt * s.W[i] * stack[(size_t)n_iters * N + i];
+    __syncthreads();
+    tinv_adj(s.t, s.c);                                            // p lives in s.c
+    for (int it = 0; it < n_iters; ++it) {
+        const double bi = (tid < N) ? stack[(size_t)(n_iters - 1 - it) * N + tid] : 0.0;     // prefetch b under the GEMV
+        gemv_cols(Sm, s.c, s.r, s.part, N, tid);                   // r = S^T p
+        for (int k = tid; k < N; k += NT) s.t[k] = ((k & 1) ? -1.0 : 1.0) * s.r[k];          // T^T r = DCT3(s o r) / N
+        __syncthreads();
+        dct3(s.w, s.t, s.g, tid);
+        if (tid < N) s.t[tid] = (4.0 * bi - 3.0 * bi * bi) * (s.g[tid] / N) + 2.0 * dt * s.W[tid] * bi;
+        __syncthreads();
+        tinv_adj(s.t, s.g);
+        for (int k = tid; k < N; k += NT) s.c[k] = s.r[k] * inv_dt + s.g[k];
+        __syncthreads();
+    }
+    for (int k = tid; k < N; k += NT) s.t[k] = ((k & 1) ? -1.0 : 1.0) * s.c[k];
+    __syncthreads();
+    dct3(s.w, s.t, s.g, tid);
+    for (int i = tid; i < N; i += NT) grad[i] = -(s.g[i] / N) / s.W[i];
+}
+
+// standalone Chebyshev maps of the reference (FWD_Solve_SHB23.py:36-67) for the parity tests against its golden vectors
+template <int NH>
+__global__ __launch_bounds__(NT) void shb_transform_kernel(const double* __restrict__ in, double* __restrict__ out, int which,
+                                                           const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
+                                                           const cplx* __restrict__ tw4_g, const double* __restrict__ W_g) {
+    constexpr int N = 2 * NH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    const int tid = threadIdx.x;
+    load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
+    for (int i = tid; i < N; i += NT) {
+        const double v = in[i], sg = (i & 1) ? -1.0 : 1.0;
+        s.t[i] = (which == 1) ? ((i == 0) ? v : 0.5 * sg * v) : ((which == 2) ? sg * v : v);
+    }
+    __syncthreads();
+    if (which == 0 || which == 3) dct2(s.w, s.t, s.g, tid); else dct3(s.w, s.t, s.g, tid);
+    for (int i = tid; i < N; i += NT) {
+        const double sg = (i & 1) ? -1.0 : 1.0;
+        double v = s.g[i];
+        if (which == 0) v *= ((i == 0) ? 0.5 : sg) / N;
+        else if (which == 2) v /= N;
+        else if (which == 3) v *= 0.5 * sg;
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void shb_inner_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ W,
+                                                        double* __restrict__ out, int N, double inv_Lz) {
+    __shared__ double red[4];
+    const size_t prob = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) acc += x[prob * N + i] * W[i] * y[prob * N + i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[prob] = (red[0] + red[1] + red[2] + red[3]) * inv_Lz;
+}
+
+class SHB23 : public Context {
+public:
+    explicit SHB23(const smo_config& c) { cfg = c; }
+    int N = 0, NH = 0;
+    double Lz = 0;
+    double *d_S = nullptr, *d_ST = nullptr, *d_W = nullptr, *d_stack = nullptr, *d_out = nullptr;
+    cplx *d_tw = nullptr, *d_twN = nullptr, *d_tw4 = nullptr;
+    int k_fwd = -1, k_adj = -1;
+
+    int init() override {
+        N = cfg.npts;
+        NH = N / 2;
+        if (N < 64 || N > 1024 || (N & (N - 1)) != 0) {
+            set_error("SHB23: npts must be a power of two in [64, 1024], got %d", N);
+            return SMO_ERR_UNSUPPORTED;
+        }
+        Lz = cfg.x1 - cfg.x0;
+        n_comp = 1;
+        vec_len = (size_t)N;
+        snapshot_doubles = (size_t)N;
+        stack_bytes = (size_t)cfg.batch * (cfg.n_iters + 1) * N * sizeof(double);
+        SMO_TRY(base_init());
+        std::vector<double> S, ST((size_t)N * N), z(N), W(N);
+        SMO_TRY(build_tau_operator(N, cfg.dt, cfg.param, cfg.x0, cfg.x1, S));
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) ST[(size_t)j * N + i] = S[(size_t)i * N + j];
+        // ascending Gauss-Chebyshev grid and the reference's trapezoid-like weights (FWD_Solve_SHB23.py:69-81)
+        const double zc = 0.5 * (cfg.x0 + cfg.x1), zh = 0.5 * (cfg.x1 - cfg.x0);
+        for (int i = 0; i < N; ++i) z[i] = zc + zh * (-std::cos(M_PI * (i + 0.5) / N));
+        W[0] = 0.5 * (z[1] - z[0]);
+        W[N - 1] = 0.5 * (z[N - 1] - z[N - 2]);
+        for (int i = 1; i < N - 1; ++i) W[i] = 0.5 * (z[i] - z[i - 1]) + 0.5 * (z[i + 1] - z[i]);
+        std::vector<cplx> twN = twiddles(N), t4 = twiddles(4 * N);
+        twN.resize(NH);
+        t4.resize(NH + 1);
+        SMO_TRY(pool.upload(&d_S, S, stream));
+        SMO_TRY(pool.upload(&d_ST, ST, stream));
+        SMO_TRY(pool.upload(&d_W, W, stream));
+        SMO_TRY(pool.upload(&d_tw, twiddles(NH), stream));
+        SMO_TRY(pool.upload(&d_twN, twN, stream));
+        SMO_TRY(pool.upload(&d_tw4, t4, stream));
+        SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * N));
+        SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
+        // algorithmic bytes: stack written/read once + the operator once + the vector
+        const double bytes = cfg.batch * ((double)(cfg.n_iters + 1) * N * 8.0 + N * 8.0) + (double)N * N * 8.0;
+        k_fwd = timing.add_class("shb_forward_kernel", bytes);
+        k_adj = timing.add_class("shb_adjoint_kernel", bytes);
+        return SMO_OK;
+    }
+
+    template <class F> int dispatch(F f) {
+        switch (NH) {
+            case 32: return f(std::integral_constant<int, 32>());
+            case 64: return f(std::integral_constant<int, 64>());
+            case 128: return f(std::integral_constant<int, 128>());
+            case 256: return f(std::integral_constant<int, 256>());
+            case 512: return f(std::integral_constant<int, 512>());
+        }
+        set_error("SHB23: unsupported npts %d", N);
+        return SMO_ERR_UNSUPPORTED;
+    }
+
+    int forward_dev(const double* const* X, double* J) override {
+        have_forward = false;
+        SMO_TRY(dispatch([&](auto nh) {
+            constexpr int H = decltype(nh)::value;
+            auto kern = shb_forward_kernel<H>;
+            const size_t lds = sizeof(ShbShared<H>);
+            SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ScopedTimer t(timing, k_fwd, stream);
+            hipLaunchKernelGGL(kern, dim3(cfg.batch), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                               1.0 / Lz, cfg.n_iters);
+            return SMO_OK;
+        }));
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipMemcpyAsync(J, d_out, cfg.batch * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        have_forward = true;
+        return SMO_OK;
+    }
+
+    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        if (adjoint_type != SMO_ADJ_DISCRETE) {
+            set_error("SHB23: only the Discrete adjoint is built (the Continuous path is a 'next' row, SURVEY 8f-5)");
+            return SMO_ERR_UNSUPPORTED;
+        }
+        SMO_TRY(dispatch([&](auto nh) {
+            constexpr int H = decltype(nh)::value;
+            auto kern = shb_adjoint_kernel<H>;
+            const size_t lds = sizeof(ShbShared<H>);
+            SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ScopedTimer t(timing, k_adj, stream);
+            hipLaunchKernelGGL(kern, dim3(cfg.batch), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt, cfg.n_iters);
+            return SMO_OK;
+        }));
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
+    int inner_dev(const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(shb_inner_kernel, dim3(cfg.batch), dim3(256), 0, stream, x, y, d_W, d_out, N, 1.0 / Lz);
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipMemcpyAsync(out, d_out, cfg.batch * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
+    int transform_host(int which, const double* in, double* out) override {
+        double *d_in = nullptr, *d_o = nullptr;
+        SMO_HIP(hipMalloc(&d_in, N * sizeof(double)));
+        SMO_HIP(hipMalloc(&d_o, N * sizeof(double)));
+        SMO_HIP(hipMemcpyAsync(d_in, in, N * sizeof(double), hipMemcpyHostToDevice, stream));
+        int rc = dispatch([&](auto nh) {
+            constexpr int H = decltype(nh)::value;
+            auto kern = shb_transform_kernel<H>;
+            const size_t lds = sizeof(ShbShared<H>);
+            SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, stream, d_in, d_o, which, d_tw, d_twN, d_tw4, d_W);
+            return SMO_OK;
+        });
+        if (rc == SMO_OK && hipMemcpyAsync(out, d_o, N * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) rc = SMO_ERR_HIP;
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(d_in);
+        (void)hipFree(d_o);
+        return rc;
+    }
+
+    int snapshot_read(int b, int index, double* out) override {
+        const double* src = d_stack + ((size_t)b * (cfg.n_iters + 1) + index) * N;
+        SMO_HIP(hipMemcpyAsync(out, src, N * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+};
+
+}  // namespace
+
+Context* make_shb23(const smo_config& cfg) { return new SHB23(cfg); }
+
 }  // namespace smo

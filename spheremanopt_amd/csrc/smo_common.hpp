@@ -125,6 +125,11 @@ public:
     virtual int adjoint_dev(const double* const* X, int adjoint_type, double* const* grad) = 0;
     virtual int inner_dev(const double* x, const double* y, double* out_host) = 0;
     virtual int snapshot_read(int b, int index, double* out) = 0;
+    virtual int transform_host(int which, const double* in, double* out) {
+        (void)which; (void)in; (void)out;
+        set_error("smo_transform: not available for this problem kind");
+        return SMO_ERR_UNSUPPORTED;
+    }
 
     // host-buffer variants: stage through context-owned device vectors
     int forward_host(const double* const* X, double* J);

@@ -1,0 +1,89 @@
+"""SHB23 HIP path (through the C-ABI): device Chebyshev maps against the vectors produced by the REFERENCE's own helper
+functions, and forward/adjoint against the oracle (1e-6 relative on J and grad J)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from spheremanopt_amd import _capi, shb23
+from spheremanopt_amd.test_grad import taylor_table
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def test_device_transforms_match_reference_helpers():
+    g = np.load(os.path.join(GOLDEN, "shb_helpers.npz"))
+    dom = shb23.SHBDomain(512)
+    v = g["v512"]
+    assert rel(shb23.transform(v, dom), g["T512"]) < 1e-13
+    assert rel(shb23.transformInverse(v, dom), g["Tinv512"]) < 1e-13
+    assert rel(shb23.transformAdjoint(v, dom), g["Tadj512"]) < 1e-13
+    assert rel(shb23.transformInverseAdjoint(v, dom), g["Tinvadj512"]) < 1e-13
+    assert np.array_equal(shb23.weightMatrixDisc(dom), g["W512"])
+    assert abs(shb23.Inner_Prod_Discrete(v, g["T512"], dom) - g["ip512"]) < 1e-13 * abs(g["ip512"])
+    # round trip
+    assert rel(shb23.transformInverse(shb23.transform(v, dom), dom), v) < 1e-13
+
+
+@pytest.mark.parametrize("N,n", [(64, 30), (128, 100), (256, 40), (1024, 10)])
+def test_forward_adjoint_vs_oracle(N, n):
+    from oracle import shb23 as osh
+    o = osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n)
+    X = osh.synthetic_ic(o, 42, 0.0019)
+    dom = shb23.SHBDomain(N)
+    buf = shb23.GEN_BUFFER(N, dom, n)
+    J = shb23.FWD_Solve_IVP_Discrete([X], dom, buf, n, 1e-2)
+    g = shb23.ADJ_Solve_IVP_Discrete([X], dom, buf, n, 1e-2)
+    Jo = o.forward([X]); go = o.adjoint([X])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert len(g) == 1 and rel(g[0], go[0]) < RTOL, rel(g[0], go[0])
+    for i in (0, 1, -1, -2):
+        assert rel(buf['A_fwd'][:, i], o.stack[:, i]) < 1e-8
+    assert abs(shb23.Inner_Prod(X, g[0], dom) - o.inner(X, go[0])) <= RTOL * abs(o.inner(X, go[0]))
+
+
+def test_config3_against_committed_oracle_output():
+    """BASELINE config 3: N=512 (Npts=256 x dealias 2), dt=0.01, T=20 (2000 steps)."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_shb23_c3.npz"))
+    dom = shb23.SHBDomain(512)
+    buf = shb23.GEN_BUFFER(512, dom, 2000)
+    X = gold["X"]
+    J = shb23.FWD_Solve([X], dom, buf, 2000)
+    g = shb23.ADJ_Solve([X], dom, buf, 2000)[0]
+    assert abs(J - gold["J"]) <= RTOL * abs(gold["J"])
+    assert rel(g, gold["grad"]) < RTOL
+    assert rel(buf['A_fwd'][:, -1], gold["stack_last"]) < 1e-8
+
+
+def test_taylor_and_ic_generation():
+    dom, X = shb23.Generate_IC(128, M_0=0.0019, seed=42)
+    _, dX = shb23.Generate_IC(128, M_0=0.0019, seed=7)
+    assert abs(shb23.Inner_Prod(X, X, dom) - 0.0019) < 1e-15
+    c = shb23.transform(X, dom)                   # the prepared IC satisfies u(20) = 0 (sum of T coefficients)
+    assert abs(c.sum()) < 1e-10 * np.abs(c).max()
+    buf = shb23.GEN_BUFFER(128, dom, 100)
+    AA = taylor_table([X], [dX], shb23.FWD_Solve, shb23.ADJ_Solve, shb23.Inner_Prod, (dom, buf, 100), (dom, 'np_vector'),
+                      epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 5e-3), AA
+
+
+def test_batch_and_errors():
+    from oracle import shb23 as osh
+    N, n, B = 64, 20, 3
+    o = osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n)
+    Xs = np.stack([osh.synthetic_ic(o, s, 0.0019) for s in range(B)])
+    ctx = shb23.SHBDomain(N).context(1e-2, n, batch=B)
+    J = ctx.forward([Xs]); g = ctx.adjoint(None)[0].reshape(B, -1)
+    for b in range(B):
+        Jo = o.forward([Xs[b]]); go = o.adjoint([Xs[b]])[0]
+        assert abs(J[b] - Jo) <= RTOL * abs(Jo) and rel(g[b], go) < RTOL
+    with pytest.raises(_capi.SmoError):
+        ctx.adjoint(None, "Continuous")
+    with pytest.raises(_capi.SmoError):
+        _capi.Context(_capi.SMO_SHB23, 48, (-20., 20.), 1e-2, 5, -0.1)
