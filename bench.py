@@ -84,6 +84,51 @@ def bench_sh23(a, torch, rank, world):
     return steps, warm, el, a.batch, roof, cfg, cpu
 
 
+def bench_shb23(a, torch, rank, world):
+    from spheremanopt_amd import shb23
+    N = a.npts or 512
+    dt, n_iters = 1e-2, a.iters or 2000
+    steps = a.steps if a.steps is not None else 20
+    warm = a.warmup if a.warmup is not None else 2
+    dom, X = shb23.Generate_IC(N, M_0=0.0019, seed=42 + rank, device=torch.cuda.current_device())
+    ctx = dom.context(dt, n_iters, batch=a.batch)
+    Xd = torch.from_numpy(np.tile(X, a.batch)).cuda()
+    Gd = torch.empty_like(Xd)
+    for _ in range(warm):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    tim = ctx.timing()
+    dom_k = max(tim, key=lambda t: t["total_ms"])
+    avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
+            "note": "latency-bound config: one workgroup per problem, %d dependent steps per launch, operator (%.1f MB) streamed from "
+                    "L2 every step; us/step = %.3f" % (n_iters, N * N * 8 / 1e6, avg_ms * 1e3 / n_iters)}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    cfg = {"workload": "Swift-Hohenberg 1D Chebyshev N=%d T=%g dt=%g discrete adjoint" % (N, dt * n_iters, dt),
+           "grid": N, "n_iters": n_iters, "batch": a.batch, "parallelism": "replicas only (x%d)" % world}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import shb23 as osh
+        o = osh.SHB23Oracle(N, dt=dt, N_ITERS=n_iters)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0 and n < 50:
+            o.forward([X]); o.adjoint([X]); n += 1
+        cpu = {"value": n / (time.perf_counter() - t0), "unit": "gradient evals/s", "cores": 1, "kind": "port",
+               "sample": "%d full forward+adjoint evaluations of the same workload (NumPy restatement)" % n}
+    return steps, warm, el, a.batch, roof, cfg, cpu
+
+
 def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
     """Oracle timed on a bounded sample: `sample_steps` forward + adjoint steps at the full grid, scaled to n_iters."""
     from oracle.kdyn import KDynOracle
@@ -165,6 +210,8 @@ def main():
     wl = a.workload or "kdyn"
     if wl == "sh23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
+    elif wl == "shb23":
+        steps, warm, el, per_step_units, roof, cfg, cpu = bench_shb23(a, torch, rank, world)
     elif wl == "kdyn":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
     else:
