@@ -21,7 +21,7 @@ ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO
 EXPORTS = [
     "smo_create", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
     "smo_stack_bytes", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
-    "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_timing_enable", "smo_timing_classes", "smo_timing_get",
+    "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
         getattr(L, name).argtypes = [vp, vp, vp, dp]
     L.smo_snapshot_read.argtypes = [vp, C.c_int, C.c_int, dp]
     L.smo_transform.argtypes = [vp, C.c_int, vp, vp]
+    L.smo_kdyn_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, dp]
+    L.smo_set_stream.argtypes = [vp, vp]
     L.smo_timing_enable.argtypes = [vp, C.c_int]
     L.smo_timing_classes.argtypes = [vp]
     L.smo_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp]

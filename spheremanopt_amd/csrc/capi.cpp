@@ -155,6 +155,18 @@ int smo_transform(smo_ctx* ctx, int which, const double* in, double* out) {
     return ctx->impl->transform_host(which, in, out);
 }
 
+int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double* out) {
+    CHECK_CTX(ctx);
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->kdyn_op(op, i0, i1, p0, p1, out);
+}
+
+int smo_set_stream(smo_ctx* ctx, void* hip_stream) {
+    CHECK_CTX(ctx);
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->set_stream(static_cast<hipStream_t>(hip_stream));
+}
+
 int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
     ctx->impl->timing.reset();

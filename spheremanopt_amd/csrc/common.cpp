@@ -82,7 +82,16 @@ Timing::~Timing() {
 // ---- context base ------------------------------------------------------------------------------------------
 Context::~Context() {
     pool.release();
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
+}
+
+int Context::set_stream(hipStream_t s) {
+    SMO_HIP(hipStreamSynchronize(stream));
+    timing.flush();
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
+    stream = s;
+    own_stream = false;
+    return SMO_OK;
 }
 
 int Context::base_init() {

@@ -8,7 +8,7 @@
 // Data layout in HBM (N = npts, a = N/2 kx modes, m = N-1 ky/kz modes, G = 3N/2 grid points per axis):
 //   coefficient fields  C [3][a][m][m]   complex128, kz fastest      (snapshot stack: [n][3][a][m][m])
 //   after the z pass    Tz[3][a][m][G]   complex128, z fastest
-//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slab-decomposed: [y-block][3][a_loc][Gy_loc][G])
+//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slab-decomposed: [peer][field][3][a_loc][Gy_loc][G])
 //   grid fields         U [3][G][G][G]   float64,    z fastest       (= the reference's flat X vectors)
 // One 3-D transform = three 1-D passes (z contiguous, y strided, x strided).  Every pass reads HBM in its first
 // Stockham stage (zero padding folded into the load) and writes HBM in its last (truncation folded into the store).
@@ -30,6 +30,7 @@ struct Geom {
     int kmax;     // (N-1)/2
     int G;        // grid points per axis (3N/2)
     int Gyl;      // local y planes in grid space (G / world)
+    size_t blk;   // slab-exchange layout: elements between the blocks of consecutive peers (= fields * 3 * al * Gyl * G)
     double Rm, dt;
 };
 
@@ -43,12 +44,12 @@ __device__ __forceinline__ double wavenumber(int idx, const Geom& g) { return (i
 // (y index) -> offset of the (c, ixl, y) line of z values in the slab-exchange layout of Ty
 __device__ __forceinline__ size_t ty_line(int c, int ixl, int y, const Geom& g) {
     const int blk = y / g.Gyl, yy = y - blk * g.Gyl;
-    return (((size_t)blk * 3 + c) * g.al + ixl) * ((size_t)g.Gyl * g.G) + (size_t)yy * g.G;
+    return (size_t)blk * g.blk + ((size_t)c * g.al + ixl) * ((size_t)g.Gyl * g.G) + (size_t)yy * g.G;
 }
 // x pass: offset of mode kx (global) of component c, flat local (y,z) index i
 __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
     const int blk = kx / g.al, kl = kx - blk * g.al;
-    return (((size_t)blk * 3 + c) * g.al + kl) * ((size_t)g.Gyl * g.G) + i;
+    return (size_t)blk * g.blk + ((size_t)c * g.al + kl) * ((size_t)g.Gyl * g.G) + i;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -400,29 +401,35 @@ class KDyn : public Context {
 public:
     explicit KDyn(const smo_config& c) { cfg = c; }
     Geom g{};
-    size_t nmode = 0, n_tz = 0, n_ty = 0, n_grid = 0;
-    cplx *d_stack = nullptr, *d_tzA = nullptr, *d_tzB = nullptr, *d_tyA = nullptr, *d_tyB = nullptr, *d_G = nullptr, *d_nu = nullptr;
-    cplx* d_tw = nullptr;
+    size_t nmode = 0, n_tz = 0, n_xb = 0, n_grid = 0, fld = 0;       // fld = 3*al*Gyl*G: one field group inside a peer block
+    cplx *d_stack = nullptr, *d_tzA = nullptr, *d_tzB = nullptr, *d_G = nullptr, *d_nu = nullptr, *d_tw = nullptr;
+    cplx *xs = nullptr, *xr = nullptr;      // exchange buffers: y-pass side / x-pass side (identical when world == 1)
     double *d_U = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1;
 
     cplx* snap(int n) { return d_stack + (size_t)n * 3 * nmode; }
+    Geom geom(int nfields) const { Geom q = g; q.blk = (size_t)nfields * fld; return q; }
 
     int init() override {
-        const int N = cfg.npts;
+        const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        if (cfg.world != 1) { set_error("KDYN: the in-library path is single-GPU; the slab-decomposed path is driven by the host layer"); return SMO_ERR_UNSUPPORTED; }
         if (N % 2 != 0 || !(N == 8 || N == 16 || N == 32 || N == 64 || N == 128 || N == 256)) {
             set_error("KDYN: npts must be one of 8,16,32,64,128,256 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
-        g.a = N / 2; g.al = g.a; g.ix0 = 0; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gyl = g.G;
+        if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 2 != 0) {
+            set_error("KDYN: %d slabs do not divide a=%d kx modes and G=%d grid planes", W, N / 2, 3 * N / 2);
+            return SMO_ERR_UNSUPPORTED;
+        }
+        g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gyl = g.G / W;
         g.Rm = cfg.param; g.dt = cfg.dt;
         nmode = (size_t)g.al * g.m * g.m;
         n_tz = (size_t)3 * g.al * g.m * g.G;
-        n_ty = (size_t)3 * g.al * g.G * g.G;
-        n_grid = (size_t)3 * g.G * g.Gyl * g.G;
+        fld = (size_t)3 * g.al * g.Gyl * g.G;
+        n_xb = 2 * fld * W;                              // two field groups (adjoint) x peers
+        n_grid = (size_t)3 * g.G * g.Gyl * g.G;          // local slab of a grid vector: [3][G][Gyl][G]
+        g.blk = fld;
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
@@ -432,14 +439,13 @@ public:
         SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nmode));
         SMO_TRY(pool.alloc(&d_tzA, n_tz));
         SMO_TRY(pool.alloc(&d_tzB, n_tz));
-        SMO_TRY(pool.alloc(&d_tyA, n_ty));
-        SMO_TRY(pool.alloc(&d_tyB, n_ty));
+        if (W == 1) { SMO_TRY(pool.alloc(&xs, n_xb)); xr = xs; }      // slabs: the host layer supplies xs / xr (SMO_KD_SET_BUFFERS)
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
         SMO_TRY(pool.alloc(&d_part, (size_t)NPART));
         h_part.resize(NPART);
-        // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component)
+        // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component, per slab)
         const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.al * (double)g.G * g.G, S3 = 8.0 * (double)g.G * g.Gyl * g.G;
         k_zi = timing.add_class("kd_z_inverse", 3 * (S0 + S1));
         k_zic = timing.add_class("kd_z_inverse<curl>", 3 * (S0 + S1));
@@ -471,6 +477,10 @@ public:
     static constexpr int YZT = 16, YNT = 256;        // y pass: 16 z columns per workgroup
     static constexpr int XNT = 384;                  // x pass: 24 FFTs per workgroup (T = 16 forward, T = 8 adjoint)
 
+    int need_buffers() {
+        if (!xs || !xr) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
+        return SMO_OK;
+    }
     int z_inverse(int mode, const cplx* in, cplx* out) {
         const int nwg = (g.al * g.m + ZNBT - 1) / ZNBT;
         return with_L([&](auto l) {
@@ -482,28 +492,33 @@ public:
             return SMO_OK;
         });
     }
-    int y_pass(bool inv, const cplx* in, cplx* out) {
+    // y pass between Tz and field group `f` of the y-side exchange buffer (layout with `nf` field groups per peer block)
+    int y_pass(bool inv, cplx* tz, int f, int nf) {
         const int nwg = 3 * g.al * ((g.G + YZT - 1) / YZT);
+        const Geom q = geom(nf);
+        cplx* ex = xs + (size_t)f * fld;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
-            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, in, out, d_tw, g);
-            else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, in, out, d_tw, g);
+            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
+            else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
             return SMO_OK;
         });
     }
-    int x_pass(int mode, cplx* specA, cplx* specB, const double* grid_in, double* grid_out) {
+    int x_pass(int mode, const double* grid_in, double* grid_out) {
         const size_t plane = (size_t)g.Gyl * g.G;
+        const Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
+        cplx *specA = xr, *specB = xr + fld;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             const int k = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
             ScopedTimer t(timing, k, stream);
             const int n16 = (int)((plane + 15) / 16), n8 = (int)((plane + 7) / 8);
             switch (mode) {
-                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
-                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, g); break;
+                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
             }
             return SMO_OK;
         });
@@ -526,48 +541,70 @@ public:
             return SMO_OK;
         });
     }
-    // grid vector (flat X layout) -> truncated coefficients
-    int grid_to_coeff(const double* X, cplx* out) {
-        SMO_TRY(x_pass(X_FROM_GRID, d_tyA, nullptr, X, nullptr));
-        SMO_TRY(y_pass(false, d_tyA, d_tzA));
-        return z_forward(ZF_PLAIN, d_tzA, nullptr, out, nullptr, nullptr, nullptr);
+
+    // ---- phases: everything between two slab exchanges (the exchange x-side <-> y-side is the host layer's job) -------
+    int fwd_A(int n) { SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA)); return y_pass(true, d_tzA, 0, 1); }
+    int fwd_B() { return x_pass(X_FUSED_FWD, d_U, nullptr); }
+    int fwd_C(int n) { SMO_TRY(y_pass(false, d_tzA, 0, 1)); return z_forward(ZF_FWD_UPDATE, d_tzA, nullptr, snap(n + 1), nullptr, snap(n), nullptr); }
+    int adj_init(int adjoint_type) {
+        ScopedTimer t(timing, k_misc, stream);
+        hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(cfg.n_iters), d_G, d_nu, g, cfg.cost == SMO_COST_INTEGRATED ? 1 : 0,
+                           adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
+        return SMO_OK;
     }
-    // coefficients -> grid vector; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
-    int coeff_to_grid(const cplx* C, double* X, bool scaled) {
-        SMO_TRY(z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, d_tzA));
-        SMO_TRY(y_pass(true, d_tzA, d_tyA));
-        return x_pass(X_TO_GRID, d_tyA, nullptr, nullptr, X);
+    int adj_A(int idx) {
+        SMO_TRY(z_inverse(ZI_CURL, d_G, d_tzA));
+        SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
+        SMO_TRY(y_pass(true, d_tzA, 0, 2));
+        return y_pass(true, d_tzB, 1, 2);
     }
-    int energy(const cplx* Bh, double* E) {
-        {
-            ScopedTimer t(timing, k_misc, stream);
-            hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, Bh, d_part, g);
-        }
+    int adj_B() { return x_pass(X_FUSED_ADJ, d_U, nullptr); }
+    int adj_C(int idx) {
+        SMO_TRY(y_pass(false, d_tzA, 0, 2));
+        SMO_TRY(y_pass(false, d_tzB, 1, 2));
+        return z_forward(ZF_ADJ_UPDATE, d_tzA, d_tzB, d_G, d_nu, d_G, snap(idx));
+    }
+    // grid vector (local slab of the flat X layout) -> truncated coefficients, in two phases around the exchange
+    int g2c_A(const double* X) { return x_pass(X_FROM_GRID, X, nullptr); }
+    int g2c_C(cplx* out) { SMO_TRY(y_pass(false, d_tzA, 0, 1)); return z_forward(ZF_PLAIN, d_tzA, nullptr, out, nullptr, nullptr, nullptr); }
+    // coefficients -> grid; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
+    int c2g_A(const cplx* C, bool scaled) { SMO_TRY(z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, d_tzA)); return y_pass(true, d_tzA, 0, 1); }
+    int c2g_B(double* X) { return x_pass(X_TO_GRID, nullptr, X); }
+
+    int reduce_partials(double* out) {
         SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
         double s = 0.0;
         for (int i = 0; i < NPART; ++i) s += h_part[i];
-        *E = s;
+        *out = s;
         return SMO_OK;
     }
+    int energy(const cplx* Bh, double* E) {            // this slab's share of sum_k w |B^|^2
+        {
+            ScopedTimer t(timing, k_misc, stream);
+            hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, Bh, d_part, g);
+        }
+        return reduce_partials(E);
+    }
 
-    // ---- the three callbacks ---------------------------------------------------------------------------------------
+    // ---- the three callbacks (single GPU: phases back to back, no exchange) -----------------------------------------
+    int single_only(const char* who) {
+        if (cfg.world != 1) { set_error("%s: with %d slabs the host layer drives the phases (smo_kdyn_op)", who, cfg.world); return SMO_ERR_STATE; }
+        return SMO_OK;
+    }
     int forward_dev(const double* const* X, double* J) override {
+        SMO_TRY(single_only("smo_forward"));
         have_forward = false;
         const int N = cfg.n_iters;
         // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver)
-        SMO_TRY(grid_to_coeff(X[1], d_G));
-        SMO_TRY(coeff_to_grid(d_G, d_U, false));
-        SMO_TRY(grid_to_coeff(X[0], snap(0)));
+        SMO_TRY(g2c_A(X[1])); SMO_TRY(g2c_C(d_G));
+        SMO_TRY(c2g_A(d_G, false)); SMO_TRY(c2g_B(d_U));
+        SMO_TRY(g2c_A(X[0])); SMO_TRY(g2c_C(snap(0)));
         double Jacc = 0.0, E = 0.0;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         for (int n = 0; n < N; ++n) {
             if (integ) { SMO_TRY(energy(snap(n), &E)); Jacc += cfg.dt * E; }
-            SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA));
-            SMO_TRY(y_pass(true, d_tzA, d_tyA));
-            SMO_TRY(x_pass(X_FUSED_FWD, d_tyA, nullptr, d_U, nullptr));
-            SMO_TRY(y_pass(false, d_tyA, d_tzA));
-            SMO_TRY(z_forward(ZF_FWD_UPDATE, d_tzA, nullptr, snap(n + 1), nullptr, snap(n), nullptr));
+            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n));
         }
         SMO_TRY(energy(snap(N), &E));
         Jacc = integ ? Jacc + cfg.dt * E : E;
@@ -579,38 +616,24 @@ public:
     }
 
     int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        SMO_TRY(single_only("smo_adjoint"));
         const int N = cfg.n_iters;
         const bool cont = adjoint_type == SMO_ADJ_CONTINUOUS;
-        const int integ = cfg.cost == SMO_COST_INTEGRATED;
-        {
-            ScopedTimer t(timing, k_misc, stream);
-            hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(N), d_G, d_nu, g, integ, cont ? 1 : 0);
-        }
+        SMO_TRY(adj_init(adjoint_type));
         int idx = cont ? N : N - 1;
-        for (int it = 0; it < N; ++it, --idx) {
-            SMO_TRY(z_inverse(ZI_CURL, d_G, d_tzA));
-            SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
-            SMO_TRY(y_pass(true, d_tzA, d_tyA));
-            SMO_TRY(y_pass(true, d_tzB, d_tyB));
-            SMO_TRY(x_pass(X_FUSED_ADJ, d_tyA, d_tyB, d_U, nullptr));
-            SMO_TRY(y_pass(false, d_tyA, d_tzA));
-            SMO_TRY(y_pass(false, d_tyB, d_tzB));
-            SMO_TRY(z_forward(ZF_ADJ_UPDATE, d_tzA, d_tzB, d_G, d_nu, d_G, snap(idx)));
-        }
-        SMO_TRY(coeff_to_grid(d_G, grad[0], !cont));
-        SMO_TRY(coeff_to_grid(d_nu, grad[1], false));
+        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(adj_A(idx)); SMO_TRY(adj_B()); SMO_TRY(adj_C(idx)); }
+        SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0]));
+        SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1]));
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
         return SMO_OK;
     }
 
-    int inner_dev(const double* x, const double* y, double* out) override {
+    int inner_dev(const double* x, const double* y, double* out) override {       // this slab's share of <x,y>
         hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
         SMO_HIP(hipGetLastError());
-        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
-        SMO_HIP(hipStreamSynchronize(stream));
         double s = 0.0;
-        for (int i = 0; i < NPART; ++i) s += h_part[i];
+        SMO_TRY(reduce_partials(&s));
         *out = s / ((double)g.G * g.G * g.G);
         return SMO_OK;
     }
@@ -619,6 +642,41 @@ public:
         SMO_HIP(hipMemcpyAsync(out, snap(index), 3 * nmode * sizeof(cplx), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
         return SMO_OK;
+    }
+
+    // ---- phase-level entry for the slab-decomposed driver (smo_kdyn_op) -------------------------------------------------
+    int kdyn_op(int op, int i0, int i1, void* p0, void* p1, double* out) override {
+        (void)i1;
+        if (op == SMO_KD_SET_BUFFERS) {
+            if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
+            xs = static_cast<cplx*>(p0); xr = static_cast<cplx*>(p1);
+            return SMO_OK;
+        }
+        if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(fld * cfg.world); return SMO_OK; }
+        SMO_TRY(need_buffers());
+        const int N = cfg.n_iters;
+        auto step_ok = [&](int n, int hi) { if (n < 0 || n > hi) { set_error("smo_kdyn_op(%d): index %d out of range", op, n); return false; } return true; };
+        int rc = SMO_OK;
+        switch (op) {
+            case SMO_KD_G2C_A: if (!p0) return SMO_ERR_ARG; rc = g2c_A(static_cast<const double*>(p0)); break;
+            case SMO_KD_G2C_C: rc = g2c_C(i0 == 0 ? snap(0) : d_G); if (i0 == 0) have_forward = false; break;
+            case SMO_KD_C2G_A: rc = c2g_A(i0 == 2 ? d_nu : d_G, i0 == 0); break;
+            case SMO_KD_C2G_B: rc = c2g_B(p0 ? static_cast<double*>(p0) : d_U); break;
+            case SMO_KD_FWD_A: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_A(i0); break;
+            case SMO_KD_FWD_B: rc = fwd_B(); break;
+            case SMO_KD_FWD_C: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_C(i0); if (i0 == N - 1) have_forward = true; break;
+            case SMO_KD_ENERGY: if (!step_ok(i0, N) || !out) return SMO_ERR_ARG; return energy(snap(i0), out);
+            case SMO_KD_ADJ_INIT:
+                if (!have_forward) { set_error("smo_kdyn_op: adjoint before forward"); return SMO_ERR_STATE; }
+                rc = adj_init(i0); break;
+            case SMO_KD_ADJ_A: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_A(i0); break;
+            case SMO_KD_ADJ_B: rc = adj_B(); break;
+            case SMO_KD_ADJ_C: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_C(i0); break;
+            case SMO_KD_SYNC: SMO_HIP(hipStreamSynchronize(stream)); break;
+            default: set_error("smo_kdyn_op: unknown op %d", op); return SMO_ERR_ARG;
+        }
+        if (rc == SMO_OK) SMO_HIP(hipGetLastError());
+        return rc;
     }
 };
 

@@ -111,6 +111,7 @@ class Context {
 public:
     smo_config cfg{};
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     DevPool pool;
     Timing timing;
     bool have_forward = false;
@@ -130,6 +131,13 @@ public:
         set_error("smo_transform: not available for this problem kind");
         return SMO_ERR_UNSUPPORTED;
     }
+
+    virtual int kdyn_op(int op, int i0, int i1, void* p0, void* p1, double* out) {
+        (void)op; (void)i0; (void)i1; (void)p0; (void)p1; (void)out;
+        set_error("smo_kdyn_op: not a KDYN context");
+        return SMO_ERR_UNSUPPORTED;
+    }
+    int set_stream(hipStream_t s);      // run on a caller-owned stream (e.g. torch's current stream) instead of the private one
 
     // host-buffer variants: stage through context-owned device vectors
     int forward_host(const double* const* X, double* J);

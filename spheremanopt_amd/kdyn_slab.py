@@ -1,0 +1,253 @@
+"""Slab-decomposed kinematic dynamo over the GPUs of one node: one process per GPU, RCCL all-to-all pencil transposes.
+
+Parallel layout (the reference gets the same decomposition implicitly from Dedalus' MPI layouts):
+  * coefficient space is split over kx   (rank r owns kx in [r*a/W, (r+1)*a/W))  -> z and y passes are local
+  * grid space is split over y           (rank r owns y  in [r*G/W, (r+1)*G/W))  -> the x pass and all grid products are local
+  * between them ONE all-to-all per direction per step, carrying all 3 (forward) / 6 (adjoint) fields at once;
+    the device kernels write/read the exchange buffers as [peer][field group][3][a/W][G/W][G], i.e. contiguous per peer.
+  * scalars (J, <x,y>) are all-reduced; the snapshot stack (1/W of it per GPU), the per-mode solves and the
+    products need no communication.
+
+The time loop only *enqueues* work: the device phases (``smo_kdyn_op``) and the collectives run on the same HIP stream
+(torch's current stream), so there is no host synchronisation inside a solve with the NCCL(=RCCL) backend.
+
+`SlabKDyn.forward / adjoint / inner` work on LOCAL slabs ([3][G][G/W][G] float64 tensors on the device).
+The module-level callables keep the reference's replicated-vector semantics (FWD_Solve_KDyn.py:91-171: every rank holds the
+full vectors; gradients are all-gathered), so ``Optimise_On_Multi_Sphere`` runs unchanged, redundantly on every rank.
+"""
+import numpy as np
+
+from . import _capi
+
+# op codes of include/smo.h
+(SET_BUFFERS, EXCHANGE_ELEMS, G2C_A, G2C_C, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, ENERGY, ADJ_INIT, ADJ_A, ADJ_B, ADJ_C,
+ SYNC) = range(15)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def rank_world():
+    try:
+        dist = _dist()
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+class HipOps:
+    """Device phases through the C-ABI (the product path)."""
+
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function, device, rank, world, stream=None):
+        import ctypes as C
+        self._C = C
+        self.ctx = _capi.Context(_capi.SMO_KDYN, Npts, (0., 2. * np.pi), dt, N_ITERS, Rm, cost=Cost_function, device=device,
+                                 rank=rank, world=world)
+        self.lib = _capi.lib()
+        if stream is not None:
+            _capi._check(self.lib.smo_set_stream(self.ctx._h, C.c_void_p(stream)))
+        out = C.c_double()
+        self.op(EXCHANGE_ELEMS, out=out)
+        self.elems = int(out.value)
+        self.vec_len = self.ctx.vec_len
+
+    def op(self, code, i0=0, p0=None, p1=None, out=None):
+        C = self._C
+        ref = C.byref(out) if out is not None else None
+        _capi._check(self.lib.smo_kdyn_op(self.ctx._h, code, int(i0), 0, C.c_void_p(p0), C.c_void_p(p1), ref))
+
+    def set_buffers(self, ys, xs):
+        self.op(SET_BUFFERS, p0=ys.data_ptr(), p1=xs.data_ptr())
+
+    def energy(self, n):
+        out = self._C.c_double()
+        self.op(ENERGY, n, out=out)
+        return out.value
+
+    def dot(self, x, y):
+        return self.ctx.inner_dev(x, y)
+
+    def phase(self, code, i0=0, vec=None):
+        self.op(code, i0, p0=(vec.data_ptr() if vec is not None else None))
+
+    def sync(self):
+        self.op(SYNC)
+
+    def snapshot(self, n):
+        return self.ctx.snapshot(n)
+
+
+class SlabKDyn:
+    """One rank's share of the forward / adjoint solve.  `ops` is the phase backend (HipOps unless a test injects its own)."""
+
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function="Final", device=None, ops=None, stage_through_host=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank_world()
+        self.N, self.G = int(Npts), 3 * int(Npts) // 2
+        self.Rm, self.dt, self.n_iters, self.cost = float(Rm), float(dt), int(N_ITERS), Cost_function
+        if (self.N // 2) % self.world or self.G % self.world:
+            raise ValueError("%d slabs do not divide a=%d / G=%d" % (self.world, self.N // 2, self.G))
+        self.Gyl = self.G // self.world
+        if ops is None:
+            if device is None:
+                device = torch.cuda.current_device()
+            self.dev = torch.device("cuda", device)
+            with torch.cuda.device(self.dev):
+                stream = torch.cuda.current_stream().cuda_stream
+            ops = HipOps(Npts, Rm, dt, N_ITERS, Cost_function, device, self.rank, self.world, stream=stream)
+        else:
+            self.dev = torch.device(getattr(ops, "device", "cpu"))
+        self.ops = ops
+        self.elems = ops.elems                                  # complex128 per field group, all peers
+        self.buf_y = torch.zeros(2 * self.elems, dtype=torch.complex128, device=self.dev)
+        self.buf_x = self.buf_y if self.world == 1 else torch.zeros_like(self.buf_y)
+        ops.set_buffers(self.buf_y, self.buf_x)
+        backend = _dist().get_backend() if self.world > 1 else None
+        # collectives on device tensors need RCCL; with gloo (CPU tests, or several ranks sharing one GPU) stage through the host
+        self.host_staged = (self.dev.type == "cuda" and backend == "gloo") if stage_through_host is None else stage_through_host
+        self.have_forward = False
+
+    # -- communication -----------------------------------------------------------------------------------------------
+    def _exchange(self, src, dst, nfields):
+        if self.world == 1:
+            return
+        n = nfields * self.elems
+        dist = _dist()
+        if self.host_staged:
+            self.ops.sync()
+            s = src[:n].cpu()
+            d = self.torch.empty_like(s)
+            dist.all_to_all_single(d, s)
+            dst[:n].copy_(d)
+        else:
+            dist.all_to_all_single(dst[:n], src[:n])
+
+    def _allreduce(self, value):
+        if self.world == 1:
+            return float(value)
+        dev = "cpu" if (self.host_staged or self.dev.type == "cpu") else self.dev
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=dev)
+        _dist().all_reduce(t)
+        return float(t.item())
+
+    # -- transforms of whole vectors ------------------------------------------------------------------------------------
+    def _grid_to_coeff(self, vec, target):
+        self.ops.phase(G2C_A, vec=vec)
+        self._exchange(self.buf_x, self.buf_y, 1)
+        self.ops.phase(G2C_C, target)
+
+    def _coeff_to_grid(self, source, vec):
+        self.ops.phase(C2G_A, source)
+        self._exchange(self.buf_y, self.buf_x, 1)
+        self.ops.phase(C2G_B, vec=vec)
+
+    # -- the three callbacks on local slabs --------------------------------------------------------------------------------
+    def forward(self, X):
+        """X = [B_local, U_local]; returns -J (identical on every rank)."""
+        B, U = X[0], X[1]
+        self.have_forward = False
+        self._grid_to_coeff(U, 1)             # U^ (truncated) -> scratch
+        self._coeff_to_grid(1, None)          # scratch -> the context's grid field U
+        self._grid_to_coeff(B, 0)             # B^_0 -> snapshot 0
+        integ = self.cost == "Integrated"
+        J = 0.0
+        for n in range(self.n_iters):
+            if integ:
+                J += self.dt * self.ops.energy(n)
+            self.ops.phase(FWD_A, n)
+            self._exchange(self.buf_y, self.buf_x, 1)
+            self.ops.phase(FWD_B)
+            self._exchange(self.buf_x, self.buf_y, 1)
+            self.ops.phase(FWD_C, n)
+        E = self.ops.energy(self.n_iters)
+        J = J + self.dt * E if integ else E
+        self.have_forward = True
+        return -self._allreduce(J)
+
+    def adjoint(self, Adjoint_type="Discrete", out=None):
+        """[dJ/dB0 local slab, dJ/dU local slab]; replays the snapshots of the last forward()."""
+        if not self.have_forward:
+            raise RuntimeError("adjoint() needs forward() first (it replays that snapshot stack)")
+        cont = Adjoint_type == "Continuous"
+        self.ops.phase(ADJ_INIT, _capi.ADJOINT[Adjoint_type])
+        idx = self.n_iters if cont else self.n_iters - 1
+        for _ in range(self.n_iters):
+            self.ops.phase(ADJ_A, idx)
+            self._exchange(self.buf_y, self.buf_x, 2)
+            self.ops.phase(ADJ_B)
+            self._exchange(self.buf_x, self.buf_y, 2)
+            self.ops.phase(ADJ_C, idx)
+            idx -= 1
+        if out is None:
+            out = [self.torch.empty(self.ops.vec_len, dtype=self.torch.float64, device=self.dev) for _ in range(2)]
+        self._coeff_to_grid(1 if cont else 0, out[0])
+        self._coeff_to_grid(2, out[1])
+        self.ops.sync()
+        return out
+
+    def inner(self, x, y):
+        return self._allreduce(self.ops.dot(x, y))
+
+    # -- replicated-vector helpers (the reference's Vec_to_Field / Field_to_Vec across ranks) ------------------------------------
+    def local_slab(self, full):
+        """Full flat vector [3][G][G][G] (NumPy or tensor, any device) -> this rank's y-slab as a flat device tensor."""
+        G, y0 = self.G, self.rank * self.Gyl
+        t = self.torch.as_tensor(np.asarray(full, dtype=np.float64) if not self.torch.is_tensor(full) else full)
+        return t.reshape(3, G, G, G)[:, :, y0:y0 + self.Gyl, :].contiguous().reshape(-1).to(self.dev)
+
+    def gather_full(self, local):
+        """Local slab -> full flat NumPy vector on every rank (all-gather over y)."""
+        G = self.G
+        loc = local.reshape(3, G, self.Gyl, G)
+        if self.world == 1:
+            return loc.reshape(-1).cpu().numpy()
+        dist = _dist()
+        staged = self.host_staged or self.dev.type == "cpu"
+        src = loc.cpu().contiguous() if staged else loc.contiguous()
+        parts = [self.torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src)
+        return self.torch.cat(parts, dim=2).reshape(-1).cpu().numpy()
+
+
+# ---- the reference's callback surface on top of the slab solver (replicated full vectors in / out) -----------------------------
+
+class SlabDomain:
+    """`domain` slot of args_f / args_IP for the multi-GPU run: caches one SlabKDyn per (Rm, dt, N_ITERS, cost)."""
+
+    def __init__(self, Npts, X=(0., 2. * np.pi), device=None):
+        self.Npts, self.interval, self.device = int(Npts), X, device
+        self.G = 3 * self.Npts // 2
+        self.hypervolume = (X[1] - X[0]) ** 3
+        self._solvers = {}
+
+    def solver(self, Rm, dt, N_ITERS, Cost_function="Final"):
+        key = (float(Rm), float(dt), int(N_ITERS), Cost_function)
+        if key not in self._solvers:
+            self._solvers[key] = SlabKDyn(self.Npts, Rm, dt, N_ITERS, Cost_function, device=self.device)
+        return self._solvers[key]
+
+    def any_solver(self):
+        if not self._solvers:
+            self.solver(1., 1e-3, 1)
+        return next(iter(self._solvers.values()))
+
+
+def FWD_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT=None, Cost_function="Final", Adjoint_type="Discrete"):
+    s = domain.solver(Rm, dt, N_ITERS, Cost_function)
+    return s.forward([s.local_slab(X0[0]), s.local_slab(X0[1])])
+
+
+def ADJ_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT=None, Cost_function="Final", Adjoint_type="Discrete"):
+    s = domain.solver(Rm, dt, N_ITERS, Cost_function)
+    g = s.adjoint(Adjoint_type)
+    return [s.gather_full(g[0]), s.gather_full(g[1])]
+
+
+def Inner_Prod_3(x, y, domain, random_arg=None):
+    s = domain.any_solver()
+    return s.inner(s.local_slab(x), s.local_slab(y))

@@ -1,0 +1,151 @@
+"""TEST INFRASTRUCTURE: a NumPy phase backend for spheremanopt_amd.kdyn_slab.SlabKDyn, used to cover the N>1 driver logic
+(exchange layout, phase order, reductions) with world_size-2 gloo runs on the CPU.  It restates, per slab, what the HIP
+phases of csrc/kdyn.hip do, reading/writing the exchange buffers in exactly their [peer][field][3][a/W][G/W][G] layout,
+and borrows the per-mode algebra from the oracle."""
+import numpy as np
+from scipy import fft as sfft
+
+from oracle.kdyn import KDynOracle
+from spheremanopt_amd.kdyn_slab import (ADJ_A, ADJ_B, ADJ_C, ADJ_INIT, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, G2C_A, G2C_C)
+
+
+class NumpyOps:
+    device = "cpu"
+
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function, rank, world):
+        o = KDynOracle(Npts, Rm=Rm, dt=dt, N_ITERS=N_ITERS, Cost_function=Cost_function)
+        self.o, self.rank, self.W = o, rank, world
+        self.G, self.a, self.m = o.G, o.a, o.m
+        self.al, self.Gyl = o.a // world, o.G // world
+        self.ix0 = rank * self.al
+        sl = slice(self.ix0, self.ix0 + self.al)
+        for name in ("K", "k2", "k2s", "zero", "alpha", "beta"):          # restrict the per-mode tables to this kx slab
+            arr = getattr(o, name)
+            setattr(o, name, arr[:, sl] if name == "K" else arr[sl])
+        self.elems = 3 * self.al * self.Gyl * self.G * world
+        self.vec_len = 3 * self.G * self.Gyl * self.G
+        self.n_iters, self.dt, self.cost = N_ITERS, dt, Cost_function
+        self.stack = np.zeros((N_ITERS + 1, 3, self.al, self.m, self.m), dtype=complex)
+        self.Gh = self.nu = self.scratch = None
+        self.U = None
+
+    # -- buffers ---------------------------------------------------------------------------------------------------------
+    def set_buffers(self, ys, xs):
+        self.by, self.bx = ys.numpy(), xs.numpy()
+
+    def _yview(self, nf):
+        return self.by[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.Gyl, self.G)
+
+    def _xview(self, nf):
+        return self.bx[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.Gyl, self.G)
+
+    def _put_y(self, Ty, f, nf):          # Ty: (3, al, G, G) -> blocks over y
+        v = Ty.reshape(3, self.al, self.W, self.Gyl, self.G).transpose(2, 0, 1, 3, 4)
+        self._yview(nf)[:, f] = v
+
+    def _get_y(self, f, nf):
+        return self._yview(nf)[:, f].transpose(1, 2, 0, 3, 4).reshape(3, self.al, self.G, self.G)
+
+    def _get_x(self, f, nf):              # -> (3, a, Gyl, G): all kx, local y
+        return self._xview(nf)[:, f].transpose(1, 0, 2, 3, 4).reshape(3, self.a, self.Gyl, self.G)
+
+    def _put_x(self, Tx, f, nf):
+        self._xview(nf)[:, f] = Tx.reshape(3, self.W, self.al, self.Gyl, self.G).transpose(1, 0, 2, 3, 4)
+
+    # -- 1-D passes on slabs -----------------------------------------------------------------------------------------------
+    def _zy_inverse(self, C):
+        o, G = self.o, self.G
+        p = np.zeros((3, self.al, self.m, G), dtype=complex); p[..., o.sel] = C
+        p = sfft.ifft(p, axis=3) * G
+        q = np.zeros((3, self.al, G, G), dtype=complex); q[:, :, o.sel] = p
+        return sfft.ifft(q, axis=2) * G
+
+    def _yz_forward(self, Ty):
+        o = self.o
+        c = sfft.fft(Ty, axis=2)[:, :, o.sel]
+        c = sfft.fft(c, axis=3)[..., o.sel]
+        return c / float(self.G) ** 3
+
+    def _x_to_grid(self, Tx):
+        G = self.G
+        r = np.zeros((3, G // 2 + 1, self.Gyl, G), dtype=complex); r[:, :self.a] = Tx
+        return sfft.irfft(r, n=G, axis=1) * G
+
+    def _x_from_grid(self, g):
+        return sfft.rfft(g, axis=1)[:, :self.a]
+
+    # -- phases ------------------------------------------------------------------------------------------------------------
+    def phase(self, code, i0=0, vec=None):
+        o = self.o
+        grid = (lambda t: t.numpy().reshape(3, self.G, self.Gyl, self.G)) if vec is not None else None
+        if code == G2C_A:
+            self._put_x(self._x_from_grid(grid(vec)), 0, 1)
+        elif code == G2C_C:
+            c = self._yz_forward(self._get_y(0, 1))
+            if i0 == 0:
+                self.stack[0] = c
+            else:
+                self.scratch = c
+        elif code == C2G_A:
+            src = {0: lambda: self.dt * o.alpha * self.Gh, 1: lambda: self.Gh if self.Gh is not None else self.scratch,
+                   2: lambda: self.nu}[i0]()
+            if i0 == 1 and self._use_scratch:
+                src = self.scratch
+            self._put_y(self._zy_inverse(src), 0, 1)
+        elif code == C2G_B:
+            g = self._x_to_grid(self._get_x(0, 1))
+            if vec is None:
+                self.U = g
+            else:
+                grid(vec)[...] = g
+        elif code == FWD_A:
+            self._put_y(self._zy_inverse(self.stack[i0]), 0, 1)
+        elif code == FWD_B:
+            Bg = self._x_to_grid(self._get_x(0, 1))
+            self._put_x(self._x_from_grid(o.cross(self.U, Bg)), 0, 1)
+        elif code == FWD_C:
+            E = self._yz_forward(self._get_y(0, 1))
+            self.stack[i0 + 1] = o.cnab_update(self.stack[i0], o.curl(E))
+        elif code == ADJ_INIT:
+            BN = self.stack[self.n_iters]
+            if i0 == 1:
+                self.Gh = -2. * BN
+            else:
+                scale = (self.dt * o.alpha) if self.cost == "Final" else o.alpha
+                self.Gh = o.project(-2. * BN) / scale
+                self.Gh[:, o.zero] = 0.
+            self.nu = np.zeros_like(self.Gh)
+            self._use_scratch = False
+        elif code == ADJ_A:
+            self._put_y(self._zy_inverse(o.curl(self.Gh)), 0, 2)
+            self._put_y(self._zy_inverse(self.stack[i0]), 1, 2)
+        elif code == ADJ_B:
+            om = self._x_to_grid(self._get_x(0, 2)); Bf = self._x_to_grid(self._get_x(1, 2))
+            self._put_x(self._x_from_grid(o.cross(om, self.U)), 0, 2)
+            self._put_x(self._x_from_grid(o.cross(om, Bf)), 1, 2)
+        elif code == ADJ_C:
+            F1 = self._yz_forward(self._get_y(0, 2)); F2 = -self._yz_forward(self._get_y(1, 2))
+            if self.cost == "Integrated":
+                F1 = F1 - 2. * self.stack[i0]
+            nu, K = self.nu, o.K
+            nu_new = nu - 2. * K * (o.kdot(nu) / o.k2s) + self.dt * o.project(F2)
+            nu_new[:, o.zero] = -nu[:, o.zero]
+            self.Gh = o.cnab_update(self.Gh, F1)
+            self.nu = nu_new
+        else:
+            raise ValueError(code)
+
+    _use_scratch = True       # before the first adjoint, C2G_A(1) means "scratch" (U^)
+
+    def energy(self, n):
+        w = np.where(self.o.K[0] == 0, 1., 2.)
+        return float((w * (np.abs(self.stack[n]) ** 2).sum(0)).sum())
+
+    def dot(self, x, y):
+        return float(np.dot(x.numpy(), y.numpy()) / float(self.G) ** 3)
+
+    def sync(self):
+        pass
+
+    def snapshot(self, n):
+        return self.stack[n]

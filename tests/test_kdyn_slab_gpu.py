@@ -1,0 +1,82 @@
+"""Slab-decomposed KDyn on real hardware.  The box has ONE GPU, so: (a) world = 1 through the phase-level C-ABI
+(smo_kdyn_op) must equal the monolithic path; (b) two processes share cuda:0 and exchange through gloo (host-staged) —
+this exercises the slab geometry of the HIP kernels (a/W kx modes, G/W y planes, per-peer blocks) against the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("cost,adj", [("Final", "Discrete"), ("Integrated", "Continuous")])
+def test_phase_path_equals_monolithic_path(cost, adj):
+    import torch
+    from spheremanopt_amd import kdyn
+    from spheremanopt_amd.kdyn_slab import SlabKDyn
+    N, n = 32, 4
+    dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, 1., 1e-3, n, n, buf, cost, adj]
+    J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    s = SlabKDyn(N, 1., 1e-3, n, cost)
+    J1 = s.forward([s.local_slab(B), s.local_slab(U)])
+    g1 = s.adjoint(adj)
+    assert J1 == J0                                     # same kernels, same order: bit-identical
+    assert np.array_equal(g1[0].cpu().numpy(), g0[0]) and np.array_equal(g1[1].cpu().numpy(), g0[1])
+    assert abs(s.inner(s.local_slab(B), g1[0]) - kdyn.Inner_Prod_3(B, g0[0], dom)) < 1e-15
+    dom.drop_contexts()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, N, n, cost, adj, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from spheremanopt_amd import kdyn, kdyn_slab
+        G = 3 * N // 2
+        B = kdyn.synthetic_field(G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * G ** 3)
+        U = kdyn.synthetic_field(G, 2)
+        dom = kdyn_slab.SlabDomain(N, device=0)
+        args = [dom, 1.3, 1e-2, n, n, None, cost, adj]
+        J = kdyn_slab.FWD_Solve_IVP_Lin([B, U], *args)              # the reference-style replicated-vector callbacks
+        gB, gU = kdyn_slab.ADJ_Solve_IVP_Lin([B, U], *args)
+        ip = kdyn_slab.Inner_Prod_3(B, gB, dom)
+        if rank == 0:
+            np.savez(out, J=J, gB=gB, gU=gU, ip=ip, B=B, U=U)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,world,cost,adj", [(16, 2, "Final", "Discrete"), (32, 4, "Integrated", "Discrete"),
+                                              (16, 2, "Final", "Continuous")])
+def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj):
+    import torch.multiprocessing as mp
+    from oracle.kdyn import KDynOracle
+    n = 3
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, out), nprocs=world, join=True)
+    r = np.load(out)
+    o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
+    Jo = o.forward([r["B"], r["U"]]); goB, goU = o.adjoint([r["B"], r["U"]], adj)
+    assert abs(float(r["J"]) - Jo) <= 1e-6 * abs(Jo)
+    assert rel(r["gB"], goB) < 1e-6 and rel(r["gU"], goU) < 1e-6
+    assert abs(float(r["ip"]) - o.inner(r["B"], goB)) <= 1e-6 * abs(o.inner(r["B"], goB))
