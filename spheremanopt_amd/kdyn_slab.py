@@ -93,18 +93,20 @@ class SlabKDyn:
         if (self.N // 2) % self.world or self.G % self.world:
             raise ValueError("%d slabs do not divide a=%d / G=%d" % (self.world, self.N // 2, self.G))
         self.Gyl = self.G // self.world
+        self.stream = None
         if ops is None:
             if device is None:
                 device = torch.cuda.current_device()
             self.dev = torch.device("cuda", device)
             with torch.cuda.device(self.dev):
-                stream = torch.cuda.current_stream().cuda_stream
-            ops = HipOps(Npts, Rm, dt, N_ITERS, Cost_function, device, self.rank, self.world, stream=stream)
+                self.stream = torch.cuda.Stream()            # kernels AND collectives are ordered on this stream
+            ops = HipOps(Npts, Rm, dt, N_ITERS, Cost_function, device, self.rank, self.world, stream=self.stream.cuda_stream)
         else:
             self.dev = torch.device(getattr(ops, "device", "cpu"))
         self.ops = ops
         self.elems = ops.elems                                  # complex128 per field group, all peers
-        self.buf_y = torch.zeros(2 * self.elems, dtype=torch.complex128, device=self.dev)
+        # exchange buffers as float64 pairs (RCCL has no complex type): 2 field groups x elems complex128
+        self.buf_y = torch.zeros(4 * self.elems, dtype=torch.float64, device=self.dev)
         self.buf_x = self.buf_y if self.world == 1 else torch.zeros_like(self.buf_y)
         ops.set_buffers(self.buf_y, self.buf_x)
         backend = _dist().get_backend() if self.world > 1 else None
@@ -116,7 +118,7 @@ class SlabKDyn:
     def _exchange(self, src, dst, nfields):
         if self.world == 1:
             return
-        n = nfields * self.elems
+        n = 2 * nfields * self.elems                           # float64 words
         dist = _dist()
         if self.host_staged:
             self.ops.sync()
@@ -147,8 +149,33 @@ class SlabKDyn:
         self.ops.phase(C2G_B, vec=vec)
 
     # -- the three callbacks on local slabs --------------------------------------------------------------------------------
+    def _on_stream(self):
+        """Context manager: make the solver's stream current (inputs produced on the caller's stream are waited for)."""
+        import contextlib
+        if self.stream is None:
+            return contextlib.nullcontext()
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
+        return self.torch.cuda.stream(self.stream)
+
+    def _done(self):
+        if self.stream is not None:
+            self.torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
     def forward(self, X):
         """X = [B_local, U_local]; returns -J (identical on every rank)."""
+        with self._on_stream():
+            J = self._forward(X)
+        self._done()
+        return J
+
+    def adjoint(self, Adjoint_type="Discrete", out=None):
+        """[dJ/dB0 local slab, dJ/dU local slab]; replays the snapshots of the last forward()."""
+        with self._on_stream():
+            g = self._adjoint(Adjoint_type, out)
+        self._done()
+        return g
+
+    def _forward(self, X):
         B, U = X[0], X[1]
         self.have_forward = False
         self._grid_to_coeff(U, 1)             # U^ (truncated) -> scratch
@@ -169,8 +196,7 @@ class SlabKDyn:
         self.have_forward = True
         return -self._allreduce(J)
 
-    def adjoint(self, Adjoint_type="Discrete", out=None):
-        """[dJ/dB0 local slab, dJ/dU local slab]; replays the snapshots of the last forward()."""
+    def _adjoint(self, Adjoint_type="Discrete", out=None):
         if not self.have_forward:
             raise RuntimeError("adjoint() needs forward() first (it replays that snapshot stack)")
         cont = Adjoint_type == "Continuous"
@@ -191,7 +217,10 @@ class SlabKDyn:
         return out
 
     def inner(self, x, y):
-        return self._allreduce(self.ops.dot(x, y))
+        with self._on_stream():
+            d = self.ops.dot(x, y)
+        self._done()
+        return self._allreduce(d)
 
     # -- replicated-vector helpers (the reference's Vec_to_Field / Field_to_Vec across ranks) ------------------------------------
     def local_slab(self, full):

@@ -31,7 +31,7 @@ class NumpyOps:
 
     # -- buffers ---------------------------------------------------------------------------------------------------------
     def set_buffers(self, ys, xs):
-        self.by, self.bx = ys.numpy(), xs.numpy()
+        self.by, self.bx = ys.numpy().view(np.complex128), xs.numpy().view(np.complex128)
 
     def _yview(self, nf):
         return self.by[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.Gyl, self.G)
