@@ -180,7 +180,7 @@ def bench_kdyn_slab(a, torch, rank, world):
                        % (N, Rm, dt * n_iters, dt),
            "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ops.ctx.stack_bytes / 1e9,
            "parallelism": "slab x%d (kx / y decomposition, RCCL all-to-all, %d field-group exchanges per step pair)" % (world, 4),
-           "exchange_MB_per_gpu_per_step_pair": 6 * 2 * s.elems * 16 / 1e6}
+           "exchange_MB_per_gpu_per_step_pair": 6 * s.elems * 16 / 1e6}
     return steps, warm, el, 1, roof, cfg, None, "strong"
 
 
