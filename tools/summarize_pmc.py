@@ -16,7 +16,8 @@ def main():
     for f in files:
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
-            short = name.split("(")[0].replace("void smo::(anonymous namespace)::", "")
+            short = name.replace("void ", "").replace("smo::(anonymous namespace)::", "")
+            short = short[:short.index(">(") + 1] if ">(" in short else short.split("(")[0]
             c = acc[short][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"]); c[1] += 1
     for k in sorted(acc):
