@@ -477,6 +477,11 @@ public:
     static constexpr int YZT = 16, YNT = 256;        // y pass: 16 z columns per workgroup
     static constexpr int XNT = 384;                  // x pass: 24 FFTs per workgroup (T = 16 forward, T = 8 adjoint)
 
+    int tune_xt = getenv("SMO_KD_XT") ? atoi(getenv("SMO_KD_XT")) : 8;      // tuning knobs (tile sizes)
+    int tune_xta = getenv("SMO_KD_XTA") ? atoi(getenv("SMO_KD_XTA")) : 4;
+    int tune_yt = getenv("SMO_KD_YT") ? atoi(getenv("SMO_KD_YT")) : 16;
+    int tune_zt = getenv("SMO_KD_ZT") ? atoi(getenv("SMO_KD_ZT")) : 4;
+
     int need_buffers() {
         if (!xs || !xr) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
         return SMO_OK;
@@ -486,6 +491,12 @@ public:
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
+            if (tune_zt == 2 && mode != ZI_SCALE) {
+                const int nw2 = (g.al * g.m + 1) / 2;
+                if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, 2, 96>), dim3(nw2), dim3(96), 0, stream, in, out, d_tw, g);
+                else hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, 2, 96>), dim3(nw2), dim3(96), 0, stream, in, out, d_tw, g);
+                return SMO_OK;
+            }
             if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
             else if (mode == ZI_CURL) hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
             else hipLaunchKernelGGL((kd_z_inverse<L, ZI_SCALE, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
@@ -494,14 +505,20 @@ public:
     }
     // y pass between Tz and field group `f` of the y-side exchange buffer (layout with `nf` field groups per peer block)
     int y_pass(bool inv, cplx* tz, int f, int nf) {
-        const int nwg = 3 * g.al * ((g.G + YZT - 1) / YZT);
+        const int yzt = (tune_yt == 8) ? 8 : YZT;
+        const int nwg = 3 * g.al * ((g.G + yzt - 1) / yzt);
         const Geom q = geom(nf);
         cplx* ex = xs + (size_t)f * fld;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
-            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
-            else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
+            if (yzt == 8) {
+                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, 8, 128>), dim3(nwg), dim3(128), 0, stream, (const cplx*)tz, ex, d_tw, q);
+                else hipLaunchKernelGGL((kd_y_pass<L, false, 8, 128>), dim3(nwg), dim3(128), 0, stream, (const cplx*)ex, tz, d_tw, q);
+            } else {
+                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
+                else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
+            }
             return SMO_OK;
         });
     }
@@ -517,8 +534,14 @@ public:
             switch (mode) {
                 case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD:
+                    if (tune_xt == 8) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 8, 192>), dim3(n8), dim3(192), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
+                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
+                    break;
+                default:
+                    if (tune_xta == 4) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 4, 192>), dim3((int)((plane + 3) / 4)), dim3(192), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
+                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
+                    break;
             }
             return SMO_OK;
         });
