@@ -64,6 +64,10 @@ typedef struct smo_config {
     /* slab decomposition of the 3-D case (one process per GPU; the exchange itself is done by the host layer):  */
     int    rank;        /* this process' slab index   (0 when world == 1) */
     int    world;       /* number of slabs            (1 = single GPU) */
+    /* windowed checkpointing of the adjoint stack (KDYN, single GPU): keep every `ckpt`-th snapshot and recompute the
+     * states in between, one window at a time, during the adjoint sweep (+ (ckpt-1)/ckpt forward steps per adjoint step).
+     * 1 = keep everything (the reference's N_SUB_ITERS = N_ITERS); 0 = smallest interval whose stack fits the free HBM. */
+    int    ckpt;
 } smo_config;
 
 /* ---- life cycle ------------------------------------------------------------------------------------------- */

@@ -34,7 +34,7 @@ class SmoError(RuntimeError):
 class smo_config(C.Structure):
     _fields_ = [("kind", C.c_int), ("npts", C.c_int), ("x0", C.c_double), ("x1", C.c_double), ("dt", C.c_double),
                 ("n_iters", C.c_int), ("param", C.c_double), ("cost", C.c_int), ("batch", C.c_int), ("device", C.c_int),
-                ("rank", C.c_int), ("world", C.c_int)]
+                ("rank", C.c_int), ("world", C.c_int), ("ckpt", C.c_int)]
 
 
 _lib = None
@@ -104,9 +104,10 @@ def _dev_ptr(t):
 class Context:
     """Owner of one smo_ctx (device buffers, twiddles, the HBM snapshot stack)."""
 
-    def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1):
+    def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1, ckpt=1):
         cfg = smo_config(kind, int(npts), float(interval[0]), float(interval[1]), float(dt), int(n_iters), float(param),
-                         COST[cost] if isinstance(cost, str) else int(cost), int(batch), int(device), int(rank), int(world))
+                         COST[cost] if isinstance(cost, str) else int(cost), int(batch), int(device), int(rank), int(world),
+                         int(ckpt))
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib().smo_create(C.byref(cfg), C.byref(self._h)))

@@ -32,7 +32,7 @@ int smo_create(const smo_config* cfg, smo_ctx** out) {
     if (!cfg || !out) { smo::set_error("smo_create: null argument"); return SMO_ERR_ARG; }
     *out = nullptr;
     if (cfg->batch < 1 || cfg->n_iters < 1 || cfg->npts < 4 || !(cfg->dt > 0) || !(cfg->x1 > cfg->x0) || cfg->world < 1 ||
-        cfg->rank < 0 || cfg->rank >= cfg->world) {
+        cfg->rank < 0 || cfg->rank >= cfg->world || cfg->ckpt < 0) {
         smo::set_error("smo_create: bad config (npts=%d n_iters=%d dt=%g batch=%d interval=[%g,%g] rank=%d/%d)", cfg->npts,
                        cfg->n_iters, cfg->dt, cfg->batch, cfg->x0, cfg->x1, cfg->rank, cfg->world);
         return SMO_ERR_ARG;

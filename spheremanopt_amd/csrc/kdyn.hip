@@ -17,6 +17,8 @@
 //   z pass  : forward z transform -> i k x (.) -> Leray projection -> CNAB1 update -> next state written straight
 //             into the snapshot stack (the stack IS the state; no copy)
 //   curl    : omega = i k x G is formed while loading the z pass of the adjoint
+#include <algorithm>
+
 #include "fft_lds.hpp"
 
 namespace smo {
@@ -408,7 +410,22 @@ public:
     std::vector<double> h_part;
     int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1;
 
-    cplx* snap(int n) { return d_stack + (size_t)n * 3 * nmode; }
+    // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time
+    int ck = 1, scratch_window = -1;
+    cplx* d_scratch = nullptr;
+    cplx* snap(int n) {
+        const int r = n % ck;
+        return r == 0 ? d_stack + (size_t)(n / ck) * 3 * nmode : d_scratch + (size_t)(r - 1) * 3 * nmode;
+    }
+    size_t stack_elems(int k) const { return ((size_t)cfg.n_iters / k + 1 + (size_t)(k - 1)) * 3 * nmode; }
+    // make state `idx` available (recompute its window from the preceding checkpoint if it is not resident)
+    int ensure(int idx) {
+        if (idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
+        const int w = idx / ck, last = std::min(cfg.n_iters, w * ck + ck - 1);
+        scratch_window = w;
+        for (int n = w * ck; n < last; ++n) { SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n)); }
+        return SMO_OK;
+    }
     Geom geom(int nfields) const { Geom q = g; q.blk = (size_t)nfields * fld; return q; }
 
     int init() override {
@@ -433,10 +450,20 @@ public:
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
-        stack_bytes = (size_t)(cfg.n_iters + 1) * 3 * nmode * sizeof(cplx);
         SMO_TRY(base_init());
+        ck = cfg.ckpt;
+        if (ck < 0 || (ck != 1 && W != 1)) { set_error("KDYN: ckpt=%d (windowed checkpointing is single-GPU only)", ck); return SMO_ERR_ARG; }
+        if (ck == 0) {                                       // smallest interval that fits the free HBM (keep 8 GB + work buffers spare)
+            size_t free_b = 0, total_b = 0;
+            SMO_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t work = (2 * n_tz + n_xb + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)8 << 30);
+            for (ck = 1; ck < cfg.n_iters && stack_elems(ck) * sizeof(cplx) + work > free_b; ++ck) {}
+        }
+        if (ck > cfg.n_iters) ck = cfg.n_iters;
+        stack_bytes = stack_elems(ck) * sizeof(cplx);
         SMO_TRY(pool.upload(&d_tw, twiddles(g.G), stream));
-        SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nmode));
+        SMO_TRY(pool.alloc(&d_stack, ((size_t)cfg.n_iters / ck + 1) * 3 * nmode));
+        if (ck > 1) SMO_TRY(pool.alloc(&d_scratch, (size_t)(ck - 1) * 3 * nmode));
         SMO_TRY(pool.alloc(&d_tzA, n_tz));
         SMO_TRY(pool.alloc(&d_tzB, n_tz));
         if (W == 1) { SMO_TRY(pool.alloc(&xs, n_xb)); xr = xs; }      // slabs: the host layer supplies xs / xr (SMO_KD_SET_BUFFERS)
@@ -629,6 +656,7 @@ public:
             if (integ) { SMO_TRY(energy(snap(n), &E)); Jacc += cfg.dt * E; }
             SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n));
         }
+        scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
         SMO_TRY(energy(snap(N), &E));
         Jacc = integ ? Jacc + cfg.dt * E : E;
         SMO_HIP(hipGetLastError());
@@ -642,9 +670,10 @@ public:
         SMO_TRY(single_only("smo_adjoint"));
         const int N = cfg.n_iters;
         const bool cont = adjoint_type == SMO_ADJ_CONTINUOUS;
+        SMO_TRY(ensure(N));
         SMO_TRY(adj_init(adjoint_type));
         int idx = cont ? N : N - 1;
-        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(adj_A(idx)); SMO_TRY(adj_B()); SMO_TRY(adj_C(idx)); }
+        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B()); SMO_TRY(adj_C(idx)); }
         SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0]));
         SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1]));
         SMO_HIP(hipGetLastError());
@@ -662,6 +691,7 @@ public:
     }
 
     int snapshot_read(int, int index, double* out) override {
+        SMO_TRY(ensure(index));
         SMO_HIP(hipMemcpyAsync(out, snap(index), 3 * nmode * sizeof(cplx), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
         return SMO_OK;

@@ -35,8 +35,10 @@ class SnapshotStack:
 
 
 class KDynDomain:
-    def __init__(self, Npts, X=(0., 2. * np.pi), device=0):
-        self.Npts, self.interval, self.device = int(Npts), (float(X[0]), float(X[1])), device
+    def __init__(self, Npts, X=(0., 2. * np.pi), device=0, ckpt=1):
+        """ckpt: keep every ckpt-th snapshot and recompute the rest during the adjoint (1 = keep all like the reference,
+        0 = smallest interval whose stack fits the free HBM)."""
+        self.Npts, self.interval, self.device, self.ckpt = int(Npts), (float(X[0]), float(X[1])), device, ckpt
         self.G = 3 * self.Npts // 2
         self.kmax = (self.Npts - 1) // 2
         self.a, self.m = self.kmax + 1, 2 * self.kmax + 1
@@ -48,7 +50,7 @@ class KDynDomain:
         key = (float(Rm), float(dt), int(N_ITERS), Cost_function)
         if key not in self._ctx:
             self._ctx[key] = _capi.Context(_capi.SMO_KDYN, self.Npts, self.interval, dt, N_ITERS, Rm, cost=Cost_function,
-                                           device=self.device)
+                                           device=self.device, ckpt=self.ckpt)
         return self._ctx[key]
 
     def drop_contexts(self):

@@ -39,10 +39,10 @@ def test_version_and_error_strings(L):
 
 def test_bad_config_rejected(L):
     h = C.c_void_p()
-    cfg = _capi.smo_config(_capi.SMO_SH23, 256, 0., 1., -1.0, 10, -0.3, 0, 1, 0, 0, 1)      # dt < 0
+    cfg = _capi.smo_config(_capi.SMO_SH23, 256, 0., 1., -1.0, 10, -0.3, 0, 1, 0, 0, 1, 1)      # dt < 0
     assert L.smo_create(C.byref(cfg), C.byref(h)) == 1 and not h.value
     assert b"bad config" in L.smo_last_error()
-    cfg = _capi.smo_config(99, 256, 0., 1., 0.1, 10, -0.3, 0, 1, 0, 0, 1)                     # unknown kind
+    cfg = _capi.smo_config(99, 256, 0., 1., 0.1, 10, -0.3, 0, 1, 0, 0, 1, 1)                     # unknown kind
     assert L.smo_create(C.byref(cfg), C.byref(h)) == 1
     assert L.smo_forward(None, None, None) == 1                                               # null context
 

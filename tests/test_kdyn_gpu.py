@@ -110,3 +110,29 @@ def test_errors():
     with pytest.raises(_capi.SmoError) as e:
         ctx.adjoint(None)
     assert e.value.code == 4
+
+
+@pytest.mark.parametrize("ckpt,n", [(2, 7), (3, 7), (4, 8), (7, 7), (0, 5)])
+@pytest.mark.parametrize("cost,adj", [("Final", "Discrete"), ("Integrated", "Continuous")])
+def test_windowed_checkpointing_is_bit_identical(ckpt, n, cost, adj):
+    """Keeping every k-th snapshot and recomputing the windows must give exactly the gradients of the keep-all run
+    (same kernels on the same data), for window sizes that do / do not divide N_ITERS."""
+    N = 16
+    ref = kdyn.KDynDomain(N)
+    B, U = _fields(ref.G, dirty=True)
+    bufr = kdyn.GEN_BUFFER(N, ref, n)
+    args = [1.0, 1e-2, n, n]
+    J0 = kdyn.FWD_Solve_IVP_Lin([B, U], ref, *args, bufr, cost, adj)
+    g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], ref, *args, bufr, cost, adj)
+    dom = kdyn.KDynDomain(N, ckpt=ckpt)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    J1 = kdyn.FWD_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)
+    g1 = kdyn.ADJ_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)
+    assert J1 == J0 and np.array_equal(g1[0], g0[0]) and np.array_equal(g1[1], g0[1])
+    g2 = kdyn.ADJ_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)          # second adjoint: windows are recomputed again
+    assert np.array_equal(g2[0], g0[0])
+    for i in (0, 1, n // 2, n - 1, n):                                       # snapshot reads recompute on demand
+        assert np.array_equal(buf['A_fwd'][:, :, :, i], bufr['A_fwd'][:, :, :, i])
+    if ckpt > 1:
+        assert dom.context(*args[:3], cost).stack_bytes < ref.context(*args[:3], cost).stack_bytes or n // ckpt + ckpt >= n + 1
+    ref.drop_contexts(); dom.drop_contexts()
