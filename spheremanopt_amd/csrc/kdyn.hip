@@ -499,53 +499,45 @@ public:
         set_error("KDYN: unsupported grid %d", g.G);
         return SMO_ERR_UNSUPPORTED;
     }
-    static constexpr int ZNBT = 4, ZNT = 192;        // z passes: 4 row triples (12 FFTs) per workgroup
-    static constexpr int ZA_NBT = 2, ZA_NT = 192;    // adjoint update: 2 row triples x 2 fields (12 FFTs)
-    static constexpr int YZT = 16, YNT = 256;        // y pass: 16 z columns per workgroup
-    static constexpr int XNT = 384;                  // x pass: 24 FFTs per workgroup (T = 16 forward, T = 8 adjoint)
-
-    int tune_xt = getenv("SMO_KD_XT") ? atoi(getenv("SMO_KD_XT")) : 8;      // tuning knobs (tile sizes)
-    int tune_xta = getenv("SMO_KD_XTA") ? atoi(getenv("SMO_KD_XTA")) : 4;
-    int tune_yt = getenv("SMO_KD_YT") ? atoi(getenv("SMO_KD_YT")) : 16;
-    int tune_zt = getenv("SMO_KD_ZT") ? atoi(getenv("SMO_KD_ZT")) : 4;
+    // Workgroup shapes.  FFTs per workgroup are halved for the long transform (G = 384) so the LDS footprint per workgroup
+    // (<= 37-49 KB => 3-4 workgroups per CU) and the butterflies per thread stay what they are at G = 192.
+    template <int L> struct Shape {
+        static constexpr int H = (L > 192) ? 2 : 1;
+        static constexpr int ZNBT = 4 / H, ZNT = 192;          // z passes: row triples per workgroup (12 / 6 FFTs)
+        static constexpr int ZA_NBT = 2 / H, ZA_NT = 192;      // adjoint update: row triples x 2 fields
+        static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
+        static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: flat (y,z) points per workgroup (12 / 6 FFTs)
+        static constexpr int XTA = 4, XANT = 192 * H;          // adjoint x pass: 12 FFTs of both field groups
+        static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
+    };
 
     int need_buffers() {
         if (!xs || !xr) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
         return SMO_OK;
     }
     int z_inverse(int mode, const cplx* in, cplx* out) {
-        const int nwg = (g.al * g.m + ZNBT - 1) / ZNBT;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
+            using S = Shape<L>;
+            const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
             ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
-            if (tune_zt == 2 && mode != ZI_SCALE) {
-                const int nw2 = (g.al * g.m + 1) / 2;
-                if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, 2, 96>), dim3(nw2), dim3(96), 0, stream, in, out, d_tw, g);
-                else hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, 2, 96>), dim3(nw2), dim3(96), 0, stream, in, out, d_tw, g);
-                return SMO_OK;
-            }
-            if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
-            else if (mode == ZI_CURL) hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
-            else hipLaunchKernelGGL((kd_z_inverse<L, ZI_SCALE, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, in, out, d_tw, g);
+            if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
+            else if (mode == ZI_CURL) hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
+            else hipLaunchKernelGGL((kd_z_inverse<L, ZI_SCALE, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
             return SMO_OK;
         });
     }
     // y pass between Tz and field group `f` of the y-side exchange buffer (layout with `nf` field groups per peer block)
     int y_pass(bool inv, cplx* tz, int f, int nf) {
-        const int yzt = (tune_yt == 8) ? 8 : YZT;
-        const int nwg = 3 * g.al * ((g.G + yzt - 1) / yzt);
         const Geom q = geom(nf);
         cplx* ex = xs + (size_t)f * fld;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
+            using S = Shape<L>;
+            const int nwg = 3 * g.al * ((g.G + S::YZT - 1) / S::YZT);
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
-            if (yzt == 8) {
-                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, 8, 128>), dim3(nwg), dim3(128), 0, stream, (const cplx*)tz, ex, d_tw, q);
-                else hipLaunchKernelGGL((kd_y_pass<L, false, 8, 128>), dim3(nwg), dim3(128), 0, stream, (const cplx*)ex, tz, d_tw, q);
-            } else {
-                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
-                else hipLaunchKernelGGL((kd_y_pass<L, false, YZT, YNT>), dim3(nwg), dim3(YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
-            }
+            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, S::YZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
+            else hipLaunchKernelGGL((kd_y_pass<L, false, S::YZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
             return SMO_OK;
         });
     }
@@ -553,22 +545,17 @@ public:
         const size_t plane = (size_t)g.Gyl * g.G;
         const Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
         cplx *specA = xr, *specB = xr + fld;
+        auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
+            using S = Shape<L>;
             const int k = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
             ScopedTimer t(timing, k, stream);
-            const int n16 = (int)((plane + 15) / 16), n8 = (int)((plane + 7) / 8);
             switch (mode) {
-                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD:
-                    if (tune_xt == 8) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 8, 192>), dim3(n8), dim3(192), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
-                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, 16, XNT>), dim3(n16), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
-                    break;
-                default:
-                    if (tune_xta == 4) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 4, 192>), dim3((int)((plane + 3) / 4)), dim3(192), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
-                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, 8, XNT>), dim3(n8), dim3(XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q);
-                    break;
+                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT>), tiles(S::XT), dim3(S::XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT>), tiles(S::XTA), dim3(S::XANT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
             }
             return SMO_OK;
         });
@@ -578,15 +565,16 @@ public:
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
+            using S = Shape<L>;
             const int k = mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc);
             ScopedTimer t(timing, k, stream);
             if (mode == ZF_ADJ_UPDATE) {
-                const int nwg = (g.al * g.m + ZA_NBT - 1) / ZA_NBT;
-                hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, ZA_NBT, ZA_NT>), dim3(nwg), dim3(ZA_NT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+                const int nwg = (g.al * g.m + S::ZA_NBT - 1) / S::ZA_NBT;
+                hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, S::ZA_NBT, S::ZA_NT>), dim3(nwg), dim3(S::ZA_NT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
             } else {
-                const int nwg = (g.al * g.m + ZNBT - 1) / ZNBT;
-                if (mode == ZF_PLAIN) hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
-                else hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, ZNBT, ZNT>), dim3(nwg), dim3(ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+                const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
+                if (mode == ZF_PLAIN) hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+                else hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
             }
             return SMO_OK;
         });
