@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmo.so")
+LIB_PATH = os.environ.get("SMO_LIB", os.path.join(_HERE, "lib", "libsmo.so"))      # SMO_LIB: experimental builds
 
 SMO_SH23, SMO_SHB23, SMO_KDYN = 1, 2, 3
 COST = {"Final": 0, "Integrated": 1}
