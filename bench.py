@@ -18,6 +18,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary (profiles/r01_kdyn128_pmc.json:
+    (2*FETCH_SIZE + WRITE_SIZE)*1024, separate counter passes); None if that kernel / size was not profiled."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_kdyn128_pmc.json")))["kernels"]
+    except Exception:
+        return None
+    k = d.get(kernel_name)
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +234,8 @@ def bench_kdyn(a, torch, rank, world):
                             for t in tim],
             "whole_gradient_algorithmic_TB": None}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    if N == 128 and world == 1:
+        roof["traffic"] = pmc_traffic(dom_k["kernel"])        # measured HBM bytes per launch (rocprofv3 PMC, profiles/)
     # whole-job figure with SURVEY 8d's per-step bytes: fwd 6T+9S3+12S0, adj 12T+15S3+24S0
     a_, m_, G_ = N // 2, N - 1, 3 * N // 2
     S0, S1, S2, S3 = 16. * a_ * m_ * m_, 16. * a_ * m_ * G_, 16. * a_ * G_ * G_, 8. * G_ ** 3
