@@ -40,6 +40,22 @@ class smo_config(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not work (the second one
+    finds no GPU), so if torch is installed its runtime is loaded first and libsmo's DT_NEEDED libamdhip64 resolves to it;
+    this keeps `import torch` (bench.py, the multi-GPU driver) usable in either import order.  torch itself is not imported."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libsmo.so once; raise loudly if it has not been built."""
     global _lib
@@ -48,6 +64,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libsmo.so not found at %s — the HIP extension is not built (run __graft_entry__.build()); "
                            "spheremanopt_amd has no CPU fallback" % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
     pp = C.POINTER(C.c_void_p)

@@ -33,6 +33,7 @@ struct Geom {
     int G;        // grid points per axis (3N/2)
     int Gyl;      // local y planes in grid space (G / world)
     size_t blk;   // slab-exchange layout: elements between the blocks of consecutive peers (= fields * 3 * al * Gyl * G)
+    int utile;    // x pass spectrum -> grid: 1 = write the tile-major layout of the internal U field (u_off), 0 = the flat X layout
     double Rm, dt;
 };
 
@@ -52,6 +53,15 @@ __device__ __forceinline__ size_t ty_line(int c, int ixl, int y, const Geom& g) 
 __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
     const int blk = kx / g.al, kl = kx - blk * g.al;
     return (size_t)blk * g.blk + ((size_t)c * g.al + kl) * ((size_t)g.Gyl * g.G) + i;
+}
+
+// The velocity field U is only ever read by the fused x passes, one (y,z) tile per workgroup, all x.  It is therefore kept
+// tile-major, U[c][i/4][x][i%4] (i = flat local (y,z) index), so that a workgroup streams it as one contiguous run instead of
+// G segments of 32-64 bytes (which cost 2-4x over-fetch of 128-byte lines).  Pairs (i, i+1) with i even never straddle a block.
+constexpr int UT = 4;
+__device__ __forceinline__ size_t u_off(int c, int x, size_t i, const Geom& g) {
+    const size_t nt = ((size_t)g.Gyl * g.G) / UT;
+    return (((size_t)c * nt + i / UT) * g.G + x) * UT + (i % UT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -239,18 +249,13 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
 enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
 
 template <int L, int MODE, int T, int NT>
-__global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut, const cplx* __restrict__ tw_g, Geom g) {
+__device__ __forceinline__ void x_tile(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut, const Geom& g,
+                                       cplx* buf, const cplx* tw, const size_t i0, const int tid) {
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
     constexpr int LD = L + 1;
-    __shared__ cplx buf[NB * LD];
-    __shared__ cplx tw[L];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
-    __syncthreads();
     const size_t plane = (size_t)g.Gyl * g.G;       // local (y,z) points
-    const size_t i0 = (size_t)blockIdx.x * T;
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
 
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const 
         fft_inplace<L, true, NB, NT, true, false, false>(buf, LD, tw, tid, ld_spec, [&](int b, int pos, cplx v) {
             const int p = b % HP, c = b / HP;
             if (line_ok(p)) {
-                double* q = gridOut + ((size_t)c * g.G + pos) * plane + i0 + 2 * p;
+                double* q = gridOut + (g.utile ? u_off(c, pos, i0 + 2 * p, g) : ((size_t)c * g.G + pos) * plane + i0 + 2 * p);
                 q[0] = v.re; q[1] = v.im;
             }
         });
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const 
             cplx A[3], U[3];                        // .re / .im = the two real lines of the pair
             for (int c = 0; c < 3; ++c) {
                 A[c] = buf[(c * HP + p) * LD + x];
-                const double* q = gridU + ((size_t)c * g.G + x) * plane + i0 + 2 * p;
+                const double* q = gridU + u_off(c, x, i0 + 2 * p, g);
                 U[c] = mk(q[0], q[1]);
             }
             if (MODE == X_FUSED_FWD) {              // EMF = U x B
@@ -333,6 +338,26 @@ __global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const 
         dst[0] = 0.5 * (Zk + Zm);
         dst[1] = mul_mi(0.5 * (Zk - Zm));
     }
+}
+
+// One tile per workgroup.  PAIRED: the tile is narrower than a 128-byte line of the spectra (T = 4 complex), so tiles 2k and
+// 2k+1 are given to workgroups b and b+8, which the dispatcher places on the same XCD at about the same time: the second
+// half of every line is then served by that XCD's L2 instead of being fetched from HBM twice (speed only, never correctness).
+template <int L, int MODE, int T, int NT, bool PAIRED = false>
+__global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut,
+                                                const cplx* __restrict__ tw_g, Geom g) {
+    constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
+    __shared__ cplx buf[NB * (L + 1)];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    __syncthreads();
+    size_t tile = blockIdx.x;
+    if (PAIRED && blockIdx.x < (gridDim.x / 16) * 16) {
+        const unsigned q = blockIdx.x / 16, r = blockIdx.x % 16;
+        tile = (size_t)q * 16 + 2 * (r % 8) + r / 8;
+    }
+    x_tile<L, MODE, T, NT>(specA, specB, gridU, gridOut, g, buf, tw, tile * T, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -435,7 +460,7 @@ public:
             set_error("KDYN: npts must be one of 8,16,32,64,128,256 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
-        if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 2 != 0) {
+        if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
             set_error("KDYN: %d slabs do not divide a=%d kx modes and G=%d grid planes", W, N / 2, 3 * N / 2);
             return SMO_ERR_UNSUPPORTED;
         }
@@ -506,8 +531,8 @@ public:
         static constexpr int ZNBT = 4 / H, ZNT = 192;          // z passes: row triples per workgroup (12 / 6 FFTs)
         static constexpr int ZA_NBT = 2 / H, ZA_NT = 192;      // adjoint update: row triples x 2 fields
         static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
-        static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: flat (y,z) points per workgroup (12 / 6 FFTs)
-        static constexpr int XTA = 4, XANT = 192 * H;          // adjoint x pass: 12 FFTs of both field groups
+        static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: (y,z) points per workgroup (12 / 6 FFTs); 128-B runs at G=192
+        static constexpr int XTA = 4, XANT = 192 * H;          // adjoint x pass: 12 FFTs of both field groups; 64-B runs, tiles paired per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
 
@@ -543,7 +568,8 @@ public:
     }
     int x_pass(int mode, const double* grid_in, double* grid_out) {
         const size_t plane = (size_t)g.Gyl * g.G;
-        const Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
+        Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
+        q.utile = (mode == X_TO_GRID && grid_out == d_U) ? 1 : 0;
         cplx *specA = xr, *specB = xr + fld;
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
@@ -554,8 +580,8 @@ public:
             switch (mode) {
                 case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT>), tiles(S::XT), dim3(S::XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT>), tiles(S::XTA), dim3(S::XANT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, (S::XT < 8)>), tiles(S::XT), dim3(S::XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, true>), tiles(S::XTA), dim3(S::XANT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
             }
             return SMO_OK;
         });
