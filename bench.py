@@ -124,8 +124,9 @@ def bench_shb23(a, torch, rank, world):
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
             "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
-            "note": "latency-bound config: one workgroup per problem, %d dependent steps per launch, operator (%.1f MB) streamed from "
-                    "L2 every step; us/step = %.3f" % (n_iters, N * N * 8 / 1e6, avg_ms * 1e3 / n_iters)}
+            "note": "latency-bound config: %d dependent steps per launch; batch 1 = a cluster of N^2/8192 workgroups with the %.1f MB "
+                    "tau operator resident in their LDS + one all-gather per step, batch > 1 = one workgroup per problem streaming "
+                    "it from L2; us/step = %.3f" % (n_iters, N * N * 8 / 1e6, avg_ms * 1e3 / n_iters)}
     roof["frac"] = roof["achieved"] / roof["peak"]
     cfg = {"workload": "Swift-Hohenberg 1D Chebyshev N=%d T=%g dt=%g discrete adjoint" % (N, dt * n_iters, dt),
            "grid": N, "n_iters": n_iters, "batch": a.batch, "parallelism": "replicas only (x%d)" % world}

@@ -187,11 +187,76 @@ __device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const do
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cluster mode (latency): KC workgroups, one per CU, co-operate on ONE problem.  Member k keeps rows [k*R, (k+1)*R) of the
+// operator resident in its LDS (N = 512: 32 members x 16 rows x 4 KB = 64 KB each) so a step no longer streams 2 MB from L2
+// through one CU; every member redundantly runs the (cheap) transforms, computes its R outputs, and the members all-gather
+// the N outputs through HBM/L2 once per step:
+//   producer: stores -> each storing lane s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent release fence, vmcnt(0),
+//             relaxed agent add on a monotonic counter
+//   consumer: lane 0 polls the counter (relaxed agent load, s_sleep, BOUNDED), agent acquire fence, vmcnt(0) -> barrier -> plain
+//             loads (cdna_hip_programming.md Guideline 16).  Outputs are double-buffered by step parity.
+// A member that times out raises `err` and every member leaves at its next gather: the kernel always terminates.
+// ---------------------------------------------------------------------------------------------------------
+struct Cluster {
+    int KC, k, R;                 // members, my index, rows per member
+    const double* Ms;             // LDS: my rows of the operator, row-major [R][N]
+    double* buf;                  // global [2][N] gathered vector (by step parity)
+    unsigned* cnt;                // global monotonic arrival counter (zeroed before the launch)
+    unsigned* err;                // global error flag
+    unsigned step;                // gathers done so far
+    int* flag;                    // LDS word for broadcasting the poll result
+};
+
+// y (LDS, full length N) <- M x with M row-sliced over the cluster; returns false on timeout (uniform over the workgroup)
+__device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double* y, int N, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    double* dst = c.buf + (size_t)(c.step & 1) * N + (size_t)c.k * c.R;
+    for (int row = wave; row < c.R; row += NT / 64) {
+        const double* m = c.Ms + (size_t)row * N;
+        double a = 0.0;
+        for (int j = lane; j < N; j += 64) a += m[j] * x[j];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if (lane == 0) {
+            __hip_atomic_store(dst + row, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (c.step + 1u) * (unsigned)c.KC;
+        int ok = 0;
+        for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+            if (__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            if (__hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) __hip_atomic_store(c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *c.flag = ok;
+    }
+    __syncthreads();
+    const bool ok = (*c.flag != 0);
+    if (ok) {
+        const double* src = c.buf + (size_t)(c.step & 1) * N;
+        for (int n = tid; n < N; n += NT) y[n] = src[n];
+    }
+    c.step += 1;
+    __syncthreads();
+    return ok;
+}
+
 template <int NH> struct ShbShared {
     DctWork<NH> w;
     double c[2 * NH], g[2 * NH], r[2 * NH], t[2 * NH], W[2 * NH];
     double part[2 * NT];
     double red[NT / 64];
+    int flag;
+    int pad_[3];
 };
 
 template <int NH> __device__ void load_tables(ShbShared<NH>& s, const cplx* tw_g, const cplx* twN_g, const cplx* tw4_g, const double* W_g, int tid) {
@@ -206,14 +271,24 @@ template <int NH>
 __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restrict__ X, double* __restrict__ stack, double* __restrict__ Jout,
                                                          const double* __restrict__ ST, const double* __restrict__ W_g,
                                                          const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
-                                                         const cplx* __restrict__ tw4_g, double dt, double inv_Lz, int n_iters) {
+                                                         const cplx* __restrict__ tw4_g, double dt, double inv_Lz, int n_iters,
+                                                         int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
+                                                         unsigned* cl_err) {
     constexpr int N = 2 * NH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
     const int tid = threadIdx.x;
-    const size_t prob = blockIdx.x;
+    const size_t prob = blockIdx.x / KC;
     X += prob * N;
     stack += prob * (size_t)(n_iters + 1) * N;
+    Cluster cl{KC, (int)(blockIdx.x % KC), N / KC, nullptr, cl_buf + prob * 2 * N, cl_cnt + prob, cl_err, 0u, &s.flag};
+    if (KC > 1) {                                    // my rows of S stay in LDS for the whole solve
+        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
+        const double* src = Mrow + (size_t)cl.k * cl.R * N;
+        for (int i = tid; i < cl.R * N; i += NT) ms[i] = src[i];
+        cl.Ms = ms;
+    }
+    const bool writer = (cl.k == 0);
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     for (int i = tid; i < N; i += NT) s.t[i] = X[i];
     __syncthreads();
@@ -230,7 +305,7 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
         dct3(s.w, s.t, s.g, tid);
         for (int i = tid; i < N; i += NT) {
             const double gi = s.g[i];
-            stack[(size_t)it * N + i] = gi;
+            if (writer) stack[(size_t)it * N + i] = gi;
             acc += s.W[i] * gi * gi;
             s.t[i] = gi * gi * (2.0 - gi);            // 2 g^2 - g^3
         }
@@ -242,12 +317,13 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
             s.r[k] = h + s.c[k] * inv_dt;
         }
         __syncthreads();
-        gemv_cols(ST, s.r, s.c, s.part, N, tid);       // c = S r
+        if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, N, tid)) return; }
+        else gemv_cols(ST, s.r, s.c, s.part, N, tid);  // c = S r
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) s.red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && writer) {
         double tot = 0.0;
         for (int i = 0; i < NT / 64; ++i) tot += s.red[i];
         Jout[prob] = -dt * inv_Lz * tot;
@@ -258,14 +334,23 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
 template <int NH>
 __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restrict__ stack, double* __restrict__ grad, const double* __restrict__ Sm,
                                                          const double* __restrict__ W_g, const cplx* __restrict__ tw_g,
-                                                         const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters) {
+                                                         const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters,
+                                                         int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
+                                                         unsigned* cl_err) {
     constexpr int N = 2 * NH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
     const int tid = threadIdx.x;
-    const size_t prob = blockIdx.x;
+    const size_t prob = blockIdx.x / KC;
     stack += prob * (size_t)(n_iters + 1) * N;
     grad += prob * N;
+    Cluster cl{KC, (int)(blockIdx.x % KC), N / KC, nullptr, cl_buf + prob * 2 * N, cl_cnt + prob, cl_err, 0u, &s.flag};
+    if (KC > 1) {                                    // my rows of S^T stay in LDS for the whole solve
+        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
+        const double* src = Mrow + (size_t)cl.k * cl.R * N;
+        for (int i = tid; i < cl.R * N; i += NT) ms[i] = src[i];
+        cl.Ms = ms;
+    }
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
     auto tinv_adj = [&](const double* in, double* out) {           // T^-T x = 1/2 s o DCT2(x), s_0 = 1
@@ -278,7 +363,8 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
     tinv_adj(s.t, s.c);                                            // p lives in s.c
     for (int it = 0; it < n_iters; ++it) {
         const double bi = (tid < N) ? stack[(size_t)(n_iters - 1 - it) * N + tid] : 0.0;     // prefetch b under the GEMV
-        gemv_cols(Sm, s.c, s.r, s.part, N, tid);                   // r = S^T p
+        if (KC > 1) { if (!cluster_gemv(cl, s.c, s.r, N, tid)) return; }
+        else gemv_cols(Sm, s.c, s.r, s.part, N, tid);              // r = S^T p
         for (int k = tid; k < N; k += NT) s.t[k] = ((k & 1) ? -1.0 : 1.0) * s.r[k];          // T^T r = DCT3(s o r) / N
         __syncthreads();
         dct3(s.w, s.t, s.g, tid);
@@ -291,7 +377,8 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
     for (int k = tid; k < N; k += NT) s.t[k] = ((k & 1) ? -1.0 : 1.0) * s.c[k];
     __syncthreads();
     dct3(s.w, s.t, s.g, tid);
-    for (int i = tid; i < N; i += NT) grad[i] = -(s.g[i] / N) / s.W[i];
+    if (cl.k == 0)
+        for (int i = tid; i < N; i += NT) grad[i] = -(s.g[i] / N) / s.W[i];
 }
 
 // standalone Chebyshev maps of the reference (FWD_Solve_SHB23.py:36-67) for the parity tests against its golden vectors
@@ -340,6 +427,9 @@ public:
     double *d_S = nullptr, *d_ST = nullptr, *d_W = nullptr, *d_stack = nullptr, *d_out = nullptr;
     cplx *d_tw = nullptr, *d_twN = nullptr, *d_tw4 = nullptr;
     int k_fwd = -1, k_adj = -1;
+    int KC = 1;                        // cluster size (1 = one workgroup per problem)
+    double* d_clbuf = nullptr;
+    unsigned *d_clcnt = nullptr, *d_clerr = nullptr;
 
     int init() override {
         N = cfg.npts;
@@ -375,6 +465,13 @@ public:
         SMO_TRY(pool.upload(&d_tw4, t4, stream));
         SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * N));
         SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
+        // latency mode: a single problem is spread over KC = N^2/8192 CUs (64 KB of operator rows per CU); SMO_SHB_CLUSTER=0 disables
+        const char* env = getenv("SMO_SHB_CLUSTER");
+        if (cfg.batch == 1 && N >= 256 && N <= 512 && !(env && atoi(env) == 0)) KC = N * N / 8192;      // N = 1024 would not fit the LDS
+        SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * N));
+        SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 1));
+        d_clerr = d_clcnt + cfg.batch;
+        SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
         // algorithmic bytes: stack written/read once + the operator once + the vector
         const double bytes = cfg.batch * ((double)(cfg.n_iters + 1) * N * 8.0 + N * 8.0) + (double)N * N * 8.0;
         k_fwd = timing.add_class("shb_forward_kernel", bytes);
@@ -399,16 +496,17 @@ public:
         SMO_TRY(dispatch([&](auto nh) {
             constexpr int H = decltype(nh)::value;
             auto kern = shb_forward_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>);
+            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(N / KC) * N * sizeof(double) : 0);
             SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
             ScopedTimer t(timing, k_fwd, stream);
-            hipLaunchKernelGGL(kern, dim3(cfg.batch), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                               1.0 / Lz, cfg.n_iters);
+            hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                               1.0 / Lz, cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr);
             return SMO_OK;
         }));
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipMemcpyAsync(J, d_out, cfg.batch * sizeof(double), hipMemcpyDeviceToHost, stream));
-        SMO_HIP(hipStreamSynchronize(stream));
+        SMO_TRY(cluster_check("forward"));
         have_forward = true;
         return SMO_OK;
     }
@@ -421,14 +519,24 @@ public:
         SMO_TRY(dispatch([&](auto nh) {
             constexpr int H = decltype(nh)::value;
             auto kern = shb_adjoint_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>);
+            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(N / KC) * N * sizeof(double) : 0);
             SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
             ScopedTimer t(timing, k_adj, stream);
-            hipLaunchKernelGGL(kern, dim3(cfg.batch), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt, cfg.n_iters);
+            hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                               cfg.n_iters, KC, d_ST, d_clbuf, d_clcnt, d_clerr);
             return SMO_OK;
         }));
         SMO_HIP(hipGetLastError());
+        return cluster_check("adjoint");
+    }
+
+    // wait for the launch and turn a cluster time-out (a member never arrived) into an error instead of garbage
+    int cluster_check(const char* who) {
+        unsigned err = 0;
+        SMO_HIP(hipMemcpyAsync(&err, d_clerr, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
+        if (err != 0) { set_error("SHB23 %s: cluster all-gather timed out (the %d workgroups were not co-resident?)", who, KC); return SMO_ERR_HIP; }
         return SMO_OK;
     }
 
