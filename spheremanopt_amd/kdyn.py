@@ -84,19 +84,69 @@ def synthetic_field(G, seed, M0=1.0):
     return v.reshape(-1)
 
 
-def Generate_IC(Npts, X=(0., 2. * np.pi), M_0=1.0, U_Noise=False, seeds=(1, 2), device=0):
-    """Domain + (B0, U) with <B0,B0> = M_0, <U,U> = 1.  U_Noise=False gives the reference's analytic flow
-    (FWD_Solve_KDyn.py:258-260, normalised); otherwise both fields are synthetic random solenoidal fields."""
+def _coeff_to_grid_host(dom, C):
+    """(a,m,m) coefficients -> (G,G,G) grid values on the host (one-off use in IC generation; NumPy, not the hot path)."""
+    G, a, kmax = dom.G, dom.a, dom.kmax
+    sel = np.concatenate([np.arange(0, kmax + 1), np.arange(G - kmax, G)])
+    p = np.zeros((G // 2 + 1, G, G), dtype=complex)
+    p[np.ix_(np.arange(a), sel, sel)] = C
+    p = np.fft.ifft(np.fft.ifft(p, axis=2), axis=1)
+    return np.fft.irfft(p, n=G, axis=0) * float(G) ** 3
+
+
+def _curl_noise(dom, seed, frac=0.25):
+    """The reference's random solenoidal field (FWD_Solve_KDyn.py:220-243): phi = filtered noise, field = grad(phi) x (1,1,1).
+    ``filter_field`` masks by INDEX fraction (> frac zeroed) on the (a, m, m) coefficient array, which removes every negative
+    ky / kz (indices beyond m/4) — reproduced deliberately."""
+    G, a, m, kmax = dom.G, dom.a, dom.m, dom.kmax
+    noise = np.random.RandomState(seed).standard_normal((G, G, G))
+    sel = np.concatenate([np.arange(0, kmax + 1), np.arange(G - kmax, G)])
+    c = np.fft.fft(np.fft.fft(np.fft.rfft(noise, axis=0)[:a], axis=1)[:, sel], axis=2)[:, :, sel] / float(G) ** 3
+    fx, fc = np.linspace(0, 1, a, endpoint=False), np.linspace(0, 1, m, endpoint=False)
+    mask = (fx[:, None, None] > frac) | (fc[None, :, None] > frac) | (fc[None, None, :] > frac)
+    c[mask] = 0j
+    kc = np.concatenate([np.arange(0, kmax + 1), np.arange(-kmax, 0)]).astype(float)
+    kx, ky, kz = np.meshgrid(np.arange(a, dtype=float), kc, kc, indexing='ij')
+    comps = [1j * (ky - kz) * c, 1j * (kz - kx) * c, 1j * (kx - ky) * c]
+    return np.stack([_coeff_to_grid_host(dom, h) for h in comps])
+
+
+def FWD_Solve_IVP_Prep(Bx0, Ux0, domain, Rm, dt, N_ITERS):
+    """Smooth B by N_ITERS+1 induction steps ON THE DEVICE; returns the three components on the grid (FWD_Solve_KDyn.py:452-527)."""
+    ctx = _capi.Context(_capi.SMO_KDYN, domain.Npts, domain.interval, dt, N_ITERS + 1, Rm, device=domain.device)
+    ctx.forward([Bx0, Ux0])
+    C = ctx.snapshot(N_ITERS + 1).view(np.complex128).reshape(3, domain.a, domain.m, domain.m)
+    ctx.close()
+    return [_coeff_to_grid_host(domain, C[i]) for i in range(3)]
+
+
+def Generate_IC(Npts, X=(0., 2. * np.pi), M_0=1.0, U_Noise=False, seeds=(1, 2), device=0, reference_recipe=False, Rm=1.0, dt=1e-3):
+    """Domain + (B0, U) with <B0,B0> = M_0, <U,U> = 1.
+    reference_recipe=False: the synthetic fields of SURVEY.md 8d (seeded, band-limited, solenoidal, mean-free) used by the tests
+    and the benchmark.  reference_recipe=True: FWD_Solve_KDyn.py:183-317 — B = curl-type field of seed-42 noise smoothed by 101
+    device steps; U = that same noise field normalised (U_Noise=True) or the analytic flow of :258-260; IC generation itself runs on
+    the host (NumPy), only the smoothing solve uses the device."""
     dom = KDynDomain(Npts, X, device=device)
     G = dom.G
-    B = synthetic_field(G, seeds[0], M_0)
-    if U_Noise:
-        U = synthetic_field(G, seeds[1], 1.0)
-    else:
-        s = X[0] + (X[1] - X[0]) * np.arange(G) / G
-        x, y, z = np.meshgrid(s, s, s, indexing='ij')
-        U = np.stack([np.sin(y) * np.cos(z), np.sin(z) * np.cos(x), np.sin(x) * np.cos(y)]) * (0.5 / np.sqrt(3.))
-        U = (U / np.sqrt(np.mean((U * U).sum(0)))).reshape(-1)
+
+    def normalise(v, val):
+        return v * np.sqrt(val / np.mean((v * v).sum(0)))
+
+    if not reference_recipe:
+        B = synthetic_field(G, seeds[0], M_0)
+        if U_Noise:
+            return dom, B, synthetic_field(G, seeds[1], 1.0)
+    if (not U_Noise) or reference_recipe:
+        if U_Noise:
+            U = normalise(_curl_noise(dom, 42), 1.0)
+        else:
+            s = X[0] + (X[1] - X[0]) * np.arange(G) / G
+            x, y, z = np.meshgrid(s, s, s, indexing='ij')
+            U = normalise(np.stack([np.sin(y) * np.cos(z), np.sin(z) * np.cos(x), np.sin(x) * np.cos(y)]) * (0.5 / np.sqrt(3.)), 1.0)
+        U = U.reshape(-1)
+    if reference_recipe:
+        B = _curl_noise(dom, 42).reshape(-1)
+        B = normalise(np.stack(FWD_Solve_IVP_Prep(B, U, dom, Rm, dt, 100)), M_0).reshape(-1)
     return dom, B, U
 
 

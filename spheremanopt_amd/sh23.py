@@ -66,12 +66,9 @@ class SH23Domain:
         return next(iter(self._ctx.values()))
 
 
-def Generate_IC(E_0=1.0, Npts=256, X=(0., 12. * np.pi), seed=42, device=0):
-    """Domain + band-limited random initial condition with <X,X> = E_0 (synthetic-input recipe of SURVEY.md 8d:
-    seeded standard-normal noise on the scale-2 grid, modes with index fraction > 1/2 removed — the reference's
-    ``filter_field`` — then normalised; the reference's extra Dedalus smoothing run, FWD_Solve_SH23.py:228, is not part
-    of the hot path)."""
-    dom = SH23Domain(Npts, X, device=device)
+def _band_limited_noise(dom, seed, E_0):
+    """Seeded standard-normal noise on the scale-2 grid, truncated to the Nc retained modes, modes with index fraction > 1/2
+    removed (the reference's ``filter_field``, FWD_Solve_SH23.py:28-53), scaled to <X,X> = E_0."""
     G, Nc = dom.G, dom.Nc
     noise = np.random.RandomState(seed).standard_normal(G)
     c = np.fft.rfft(noise) / G
@@ -79,7 +76,31 @@ def Generate_IC(E_0=1.0, Npts=256, X=(0., 12. * np.pi), seed=42, device=0):
     keep[:Nc] = np.linspace(0, 1, Nc, endpoint=False) <= 0.5
     c[~keep] = 0
     x = np.fft.irfft(c, n=G) * G
-    return dom, x * np.sqrt(E_0 / np.mean(x * x))
+    return x * np.sqrt(E_0 / np.mean(x * x))
+
+
+def FWD_Solve_IVP_PREP(X_k, domain, dt=1e-02, N_ITERS=100, N_SUB_ITERS=100):
+    """Smooth an initial condition by integrating it N_ITERS+1 steps with the forward solver ON THE DEVICE and return the
+    final state on the scale-2 grid (FWD_Solve_SH23.py:334-407; the reference's solver stops at iteration N_ITERS+1)."""
+    ctx = domain.context(dt, N_ITERS + 1)
+    ctx.forward([X_k[0]])
+    c = ctx.snapshot(N_ITERS + 1).view(np.complex128)
+    pad = np.zeros(domain.G // 2 + 1, dtype=complex)
+    pad[:domain.Nc] = c
+    pad[0] = pad[0].real
+    return np.fft.irfft(pad, n=domain.G) * domain.G
+
+
+def Generate_IC(E_0=1.0, Npts=256, X=(0., 12. * np.pi), seed=42, device=0, prep=False):
+    """Domain + initial condition with <X,X> = E_0 (FWD_Solve_SH23.py:174-236): seeded noise (seed 42 in the reference),
+    filtered, normalised; with ``prep=True`` additionally smoothed by 101 device steps at dt = 0.01 and re-normalised, which
+    is the reference's full recipe.  ``prep=False`` is the synthetic-input recipe of SURVEY.md 8d used by the tests/bench."""
+    dom = SH23Domain(Npts, X, device=device)
+    x = _band_limited_noise(dom, seed, E_0)
+    if prep:
+        x = FWD_Solve_IVP_PREP([x], dom)
+        x = x * np.sqrt(E_0 / np.mean(x * x))
+    return dom, x
 
 
 def GEN_BUFFER(domain, N_SUB_ITERS, Npts=256):

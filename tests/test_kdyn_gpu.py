@@ -136,3 +136,26 @@ def test_windowed_checkpointing_is_bit_identical(ckpt, n, cost, adj):
     if ckpt > 1:
         assert dom.context(*args[:3], cost).stack_bytes < ref.context(*args[:3], cost).stack_bytes or n // ckpt + ckpt >= n + 1
     ref.drop_contexts(); dom.drop_contexts()
+
+
+def test_reference_ic_recipe_with_device_prep():
+    """Generate_IC(reference_recipe=True): curl-type field of filtered seed-42 noise, smoothed by 101 device steps (KDYN:183-317)."""
+    N = 16
+    dom, B, U = kdyn.Generate_IC(N, U_Noise=True, reference_recipe=True, dt=1e-3)
+    o = _oracle(N, 1.0, 1e-3, 101, "Final")
+    assert abs(o.inner(B, B) - 1) < 1e-12 and abs(o.inner(U, U) - 1) < 1e-12
+    Bh = o.vec_to_coeff(B)
+    assert np.abs(o.kdot(Bh)).max() < 1e-12 * np.abs(Bh).max()                   # solenoidal
+    # the smoothing solve is the device forward solver: compare with the oracle run from the same raw field
+    raw = kdyn._curl_noise(dom, 42).reshape(-1)
+    Rh = o.vec_to_coeff(raw)
+    assert np.abs(Rh[1:, 1:, o.kmax + 1:, :]).max() < 1e-12 * np.abs(Rh).max()   # index-fraction filter: no negative ky for kx > 0
+    assert np.abs(o.kdot(Rh)).max() < 1e-12 * np.abs(Rh).max()
+    o.forward([raw, U])
+    ref = o.coeff_to_vec(o.stack[..., 101])
+    ref *= 1. / np.sqrt(o.inner(ref, ref))
+    assert rel(B, ref) < 1e-9
+    dom.drop_contexts()
+    # analytic flow variant
+    _, _, Ua = kdyn.Generate_IC(N, U_Noise=False)
+    assert abs(o.inner(Ua, Ua) - 1) < 1e-12

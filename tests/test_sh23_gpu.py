@@ -115,3 +115,15 @@ def test_optimiser_runs_on_device_callbacks(in_tmp_cwd):
     assert np.allclose(FUN, FUNo, rtol=1e-9) and np.allclose(RES, RESo, rtol=1e-6)
     assert rel(Xopt[0], Xo[0]) < 1e-8
     assert all(FUN[i + 1] >= FUN[i] for i in range(len(FUN) - 1))       # FUNCT stores -J_k = +J_phys: increasing
+
+
+def test_reference_ic_recipe_with_device_prep():
+    """Generate_IC(prep=True): noise -> filter -> normalise -> 101 device steps at dt=0.01 -> normalise (SH23:174-236)."""
+    dom, X = sh23.Generate_IC(0.0725, Npts=128, prep=True)
+    assert abs(np.mean(X * X) - 0.0725) < 1e-15
+    _, X0 = sh23.Generate_IC(0.0725, Npts=128, prep=False)
+    o = _oracle(128, 0.01, 101)
+    o.forward([X0])
+    ref = o.to_grid(o.stack[:, 101])
+    ref *= np.sqrt(0.0725 / np.mean(ref * ref))
+    assert rel(X, ref) < 1e-9
