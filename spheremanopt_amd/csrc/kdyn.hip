@@ -433,6 +433,7 @@ public:
     cplx *xs = nullptr, *xr = nullptr;      // exchange buffers: y-pass side / x-pass side (identical when world == 1)
     double *d_U = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
+    size_t n_part_rows = 1;
     int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1;
 
     // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time
@@ -495,8 +496,9 @@ public:
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
-        SMO_TRY(pool.alloc(&d_part, (size_t)NPART));
-        h_part.resize(NPART);
+        n_part_rows = (cfg.cost == SMO_COST_INTEGRATED && W == 1) ? (size_t)cfg.n_iters + 1 : 1;
+        SMO_TRY(pool.alloc(&d_part, n_part_rows * NPART));
+        h_part.resize(n_part_rows * NPART);
         // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component, per slab)
         const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.al * (double)g.G * g.G, S3 = 8.0 * (double)g.G * g.Gyl * g.G;
         k_zi = timing.add_class("kd_z_inverse", 3 * (S0 + S1));
@@ -667,12 +669,29 @@ public:
         double Jacc = 0.0, E = 0.0;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         for (int n = 0; n < N; ++n) {
-            if (integ) { SMO_TRY(energy(snap(n), &E)); Jacc += cfg.dt * E; }
+            if (integ) {                                   // <B_n,B_n> partial sums stay on the device until the end of the solve
+                ScopedTimer t(timing, k_misc, stream);
+                hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(n), d_part + (size_t)n * NPART, g);
+            }
             SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n));
         }
         scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
-        SMO_TRY(energy(snap(N), &E));
-        Jacc = integ ? Jacc + cfg.dt * E : E;
+        if (integ) {
+            {
+                ScopedTimer t(timing, k_misc, stream);
+                hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(N), d_part + (size_t)N * NPART, g);
+            }
+            SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, (size_t)(N + 1) * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+            SMO_HIP(hipStreamSynchronize(stream));
+            for (int n = 0; n <= N; ++n) {
+                double e = 0.0;
+                for (int i = 0; i < NPART; ++i) e += h_part[(size_t)n * NPART + i];
+                Jacc += cfg.dt * e;
+            }
+        } else {
+            SMO_TRY(energy(snap(N), &E));
+            Jacc = E;
+        }
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
         *J = -Jacc;
