@@ -206,8 +206,7 @@ def bench_kdyn(a, torch, rank, world):
     dom, B, U = kdyn.Generate_IC(N, U_Noise=True, device=torch.cuda.current_device())
     dom.ckpt = 0                              # keep every snapshot if the stack fits the HBM, else the smallest window that does
     ctx = dom.context(Rm, dt, n_iters, "Final")
-    snap_bytes = 3 * (N // 2) * (N - 1) ** 2 * 16
-    ck = next(k for k in range(1, n_iters + 1) if (n_iters // k + 1 + k - 1) * snap_bytes == ctx.stack_bytes)
+    ck = int(ctx.get(0))
     Bd, Ud = torch.from_numpy(B).cuda(), torch.from_numpy(U).cuda()
     gB, gU = torch.empty_like(Bd), torch.empty_like(Ud)
     for _ in range(warm):
@@ -250,7 +249,7 @@ def bench_kdyn(a, torch, rank, world):
     roof["whole_gradient_GBps"] = per_grad / (el / steps) / 1e9
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
-           "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "checkpoint_interval": ck, "J": J,
+           "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "checkpoint_interval": ck, "y_side_stack_GB": ctx.get(1) / 1e9, "J": J,
            "parallelism": "1 GPU" if world == 1 else "replicas only (x%d independent gradients)" % world}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

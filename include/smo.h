@@ -80,7 +80,10 @@ int         smo_device_count(int* count);                      /* never initiali
 /* ---- geometry --------------------------------------------------------------------------------------------- */
 int smo_ncomp(const smo_ctx* ctx);                              /* number of norm-constrained vectors (1 or 2) */
 int smo_vec_len(const smo_ctx* ctx, size_t* len);               /* doubles per component (per batch member) */
-int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* size of the HBM-resident snapshot stack */
+int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by the snapshot stack(s) */
+/* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: bytes of the y-side stack kept by the forward
+ * solve so that the adjoint skips the z/y passes of every snapshot (KDYN, 0 if not in use). */
+int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */
 int smo_forward(smo_ctx* ctx, const double* const* X, double* J);
@@ -119,12 +122,12 @@ enum {
     SMO_KD_C2G_A = 4,         /* i0 = 0: dt*alpha*G^ (discrete grad B), 1: G^/scratch, 2: nu^ ; z,y passes  [then exchange y->x] */
     SMO_KD_C2G_B = 5,         /* x pass spectrum -> grid; p0 = output local grid vector, NULL = the context's U field           */
     SMO_KD_FWD_A = 6,         /* i0 = step n: z,y inverse passes of snapshot n                              [exchange y->x, 1 group] */
-    SMO_KD_FWD_B = 7,         /* fused x pass (c2r, U x B, r2c)                                             [exchange x->y, 1 group] */
+    SMO_KD_FWD_B = 7,         /* i0 = n: fused x pass (c2r, U x B, r2c)                                     [exchange x->y, 1 group] */
     SMO_KD_FWD_C = 8,         /* i0 = n: y,z forward passes + CNAB1 update -> snapshot n+1                                         */
     SMO_KD_ENERGY = 9,        /* i0 = n: out <- this slab's share of <B_n,B_n> (synchronises)                                      */
     SMO_KD_ADJ_INIT = 10,     /* i0 = adjoint_type: terminal condition from snapshot N                                             */
     SMO_KD_ADJ_A = 11,        /* i0 = snapshot index: curl(G^) and B_f through z,y inverse passes          [exchange y->x, 2 groups] */
-    SMO_KD_ADJ_B = 12,        /* fused x pass (6 c2r, two cross products, 6 r2c)                           [exchange x->y, 2 groups] */
+    SMO_KD_ADJ_B = 12,        /* i0 = snapshot index: fused x pass (6 c2r, two cross products, 6 r2c)      [exchange x->y, 2 groups] */
     SMO_KD_ADJ_C = 13,        /* i0 = snapshot index: y,z forward passes + G^, nu^ updates                                         */
     SMO_KD_SYNC = 14          /* wait for the context's stream                                                                     */
 };

@@ -20,7 +20,7 @@ ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO
 
 EXPORTS = [
     "smo_create", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
-    "smo_stack_bytes", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
+    "smo_stack_bytes", "smo_get", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
     "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get",
 ]
 
@@ -78,6 +78,7 @@ def lib():
     L.smo_vec_len.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.smo_stack_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.smo_snapshot_len.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.smo_get.argtypes = [vp, C.c_int, dp]
     for name in ("smo_forward", "smo_forward_dev"):
         getattr(L, name).argtypes = [vp, pp, dp]
     for name in ("smo_adjoint", "smo_adjoint_dev"):
@@ -209,6 +210,11 @@ class Context:
         out = np.empty_like(x)
         _check(lib().smo_transform(self._h, int(which), x.ctypes.data, out.ctypes.data))
         return out
+
+    def get(self, key):
+        v = C.c_double()
+        _check(lib().smo_get(self._h, int(key), C.byref(v)))
+        return v.value
 
     def timing_enable(self, on=True):
         _check(lib().smo_timing_enable(self._h, 1 if on else 0))

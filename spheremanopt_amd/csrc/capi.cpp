@@ -75,6 +75,13 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes) {
     return SMO_OK;
 }
 
+int smo_get(const smo_ctx* ctx, int key, double* value) {
+    CHECK_CTX(ctx);
+    if (!value || key < 0 || key > 1) { smo::set_error("smo_get: bad argument"); return SMO_ERR_ARG; }
+    *value = ctx->impl->info(key);
+    return SMO_OK;
+}
+
 static int check_vecs(const smo_ctx* ctx, const double* const* X, const char* who) {
     if (!X) { smo::set_error("%s: null vector list", who); return SMO_ERR_ARG; }
     for (int c = 0; c < ctx->impl->n_comp; ++c)

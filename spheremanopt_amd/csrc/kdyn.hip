@@ -248,8 +248,16 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
 // ---------------------------------------------------------------------------------------------------------
 enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
 
+// spectra of the x pass: field groups A / B are read from in* and written to out* (same layout; in == out means in place)
+struct XSpec {
+    const cplx* inA;
+    const cplx* inB;
+    cplx* outA;
+    cplx* outB;
+};
+
 template <int L, int MODE, int T, int NT>
-__device__ __forceinline__ void x_tile(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut, const Geom& g,
+__device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
                                        cplx* buf, const cplx* tw, const size_t i0, const int tid) {
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
@@ -263,7 +271,7 @@ __device__ __forceinline__ void x_tile(cplx* specA, cplx* specB, const double* _
     auto ld_spec = [&](int b, int pos) -> cplx {
         const int p = b % HP, fc = b / HP, c = fc % 3, f = fc / 3;
         if (!line_ok(p)) return mk(0, 0);
-        const cplx* src = (f == 0) ? specA : specB;
+        const cplx* src = (f == 0) ? sp.inA : sp.inB;
         int kx; bool cj;
         if (pos < g.a) { kx = pos; cj = false; }
         else if (pos > g.G - g.a) { kx = g.G - pos; cj = true; }
@@ -334,7 +342,7 @@ __device__ __forceinline__ void x_tile(cplx* specA, cplx* specB, const double* _
         const int c = fc % 3, f = fc / 3;
         const cplx Zk = buf[(fc * HP + p) * LD + kx];
         const cplx Zm = conj(buf[(fc * HP + p) * LD + ((kx == 0) ? 0 : L - kx)]);
-        cplx* dst = ((f == 0) ? specA : specB) + tx_off(c, kx, i0 + 2 * p, g);
+        cplx* dst = ((f == 0) ? sp.outA : sp.outB) + tx_off(c, kx, i0 + 2 * p, g);
         dst[0] = 0.5 * (Zk + Zm);
         dst[1] = mul_mi(0.5 * (Zk - Zm));
     }
@@ -344,7 +352,7 @@ __device__ __forceinline__ void x_tile(cplx* specA, cplx* specB, const double* _
 // 2k+1 are given to workgroups b and b+8, which the dispatcher places on the same XCD at about the same time: the second
 // half of every line is then served by that XCD's L2 instead of being fetched from HBM twice (speed only, never correctness).
 template <int L, int MODE, int T, int NT, bool PAIRED = false>
-__global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const double* __restrict__ gridU, double* gridOut,
+__global__ __launch_bounds__(NT) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
     __shared__ cplx buf[NB * (L + 1)];
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(NT) void kd_x_pass(cplx* specA, cplx* specB, const 
         const unsigned q = blockIdx.x / 16, r = blockIdx.x % 16;
         tile = (size_t)q * 16 + 2 * (r % 8) + r / 8;
     }
-    x_tile<L, MODE, T, NT>(specA, specB, gridU, gridOut, g, buf, tw, tile * T, tid);
+    x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, tw, tile * T, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -490,6 +498,17 @@ public:
         SMO_TRY(pool.upload(&d_tw, twiddles(g.G), stream));
         SMO_TRY(pool.alloc(&d_stack, ((size_t)cfg.n_iters / ck + 1) * 3 * nmode));
         if (ck > 1) SMO_TRY(pool.alloc(&d_scratch, (size_t)(ck - 1) * 3 * nmode));
+        {   // Ty stack: only when every snapshot is kept, on one GPU, and 16 GB of HBM stay free afterwards (SMO_KD_TYSTACK=0 disables)
+            const char* env = getenv("SMO_KD_TYSTACK");
+            size_t free_b = 0, total_b = 0;
+            SMO_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t need = (size_t)cfg.n_iters * fld * sizeof(cplx);
+            const size_t rest = (2 * n_tz + n_xb + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)16 << 30);
+            if (W == 1 && ck == 1 && !(env && atoi(env) == 0) && need + rest < free_b) {
+                SMO_TRY(pool.alloc(&d_tystack, (size_t)cfg.n_iters * fld));
+                stack_bytes += need;
+            }
+        }
         SMO_TRY(pool.alloc(&d_tzA, n_tz));
         SMO_TRY(pool.alloc(&d_tzB, n_tz));
         if (W == 1) { SMO_TRY(pool.alloc(&xs, n_xb)); xr = xs; }      // slabs: the host layer supplies xs / xr (SMO_KD_SET_BUFFERS)
@@ -555,9 +574,9 @@ public:
         });
     }
     // y pass between Tz and field group `f` of the y-side exchange buffer (layout with `nf` field groups per peer block)
-    int y_pass(bool inv, cplx* tz, int f, int nf) {
+    int y_pass(bool inv, cplx* tz, int f, int nf, cplx* ex_override = nullptr) {
         const Geom q = geom(nf);
-        cplx* ex = xs + (size_t)f * fld;
+        cplx* ex = ex_override ? ex_override : xs + (size_t)f * fld;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -568,11 +587,12 @@ public:
             return SMO_OK;
         });
     }
-    int x_pass(int mode, const double* grid_in, double* grid_out) {
+    // inA / inB: read the spectra of field group A / B from elsewhere (e.g. the Ty stack) instead of the x-side buffer
+    int x_pass(int mode, const double* grid_in, double* grid_out, const cplx* inA = nullptr, const cplx* inB = nullptr) {
         const size_t plane = (size_t)g.Gyl * g.G;
         Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
         q.utile = (mode == X_TO_GRID && grid_out == d_U) ? 1 : 0;
-        cplx *specA = xr, *specB = xr + fld;
+        const XSpec sp{inA ? inA : xr, inB ? inB : xr + fld, xr, xr + fld};
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
@@ -580,10 +600,10 @@ public:
             const int k = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
             ScopedTimer t(timing, k, stream);
             switch (mode) {
-                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, (S::XT < 8)>), tiles(S::XT), dim3(S::XNT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, true>), tiles(S::XTA), dim3(S::XANT), 0, stream, specA, specB, grid_in, grid_out, d_tw, q); break;
+                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, (S::XT < 8)>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, true>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
             }
             return SMO_OK;
         });
@@ -609,8 +629,13 @@ public:
     }
 
     // ---- phases: everything between two slab exchanges (the exchange x-side <-> y-side is the host layer's job) -------
-    int fwd_A(int n) { SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA)); return y_pass(true, d_tzA, 0, 1); }
-    int fwd_B() { return x_pass(X_FUSED_FWD, d_U, nullptr); }
+    // Ty stack (single GPU, keep-all): the y-pass output of B^_n is written to its own HBM slot instead of the exchange buffer; the
+    // adjoint step then reads B_f from there and skips the z and y passes of the snapshot (2 of its 8 kernels).
+    cplx* d_tystack = nullptr;
+    cplx* tyslot(int n) { return d_tystack + (size_t)n * fld; }
+    bool have_ty(int n) const { return d_tystack != nullptr && n < cfg.n_iters; }
+    int fwd_A(int n) { SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA)); return y_pass(true, d_tzA, 0, 1, have_ty(n) ? tyslot(n) : nullptr); }
+    int fwd_B(int n = -1) { return x_pass(X_FUSED_FWD, d_U, nullptr, (n >= 0 && have_ty(n)) ? tyslot(n) : nullptr); }
     int fwd_C(int n) { SMO_TRY(y_pass(false, d_tzA, 0, 1)); return z_forward(ZF_FWD_UPDATE, d_tzA, nullptr, snap(n + 1), nullptr, snap(n), nullptr); }
     int adj_init(int adjoint_type) {
         ScopedTimer t(timing, k_misc, stream);
@@ -620,11 +645,12 @@ public:
     }
     int adj_A(int idx) {
         SMO_TRY(z_inverse(ZI_CURL, d_G, d_tzA));
-        SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
         SMO_TRY(y_pass(true, d_tzA, 0, 2));
+        if (have_ty(idx)) return SMO_OK;               // B_f on the y side was kept by the forward solve
+        SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
         return y_pass(true, d_tzB, 1, 2);
     }
-    int adj_B() { return x_pass(X_FUSED_ADJ, d_U, nullptr); }
+    int adj_B(int idx = -1) { return x_pass(X_FUSED_ADJ, d_U, nullptr, nullptr, (idx >= 0 && have_ty(idx)) ? tyslot(idx) : nullptr); }
     int adj_C(int idx) {
         SMO_TRY(y_pass(false, d_tzA, 0, 2));
         SMO_TRY(y_pass(false, d_tzB, 1, 2));
@@ -673,7 +699,7 @@ public:
                 ScopedTimer t(timing, k_misc, stream);
                 hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(n), d_part + (size_t)n * NPART, g);
             }
-            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n));
+            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(n)); SMO_TRY(fwd_C(n));
         }
         scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
         if (integ) {
@@ -706,7 +732,7 @@ public:
         SMO_TRY(ensure(N));
         SMO_TRY(adj_init(adjoint_type));
         int idx = cont ? N : N - 1;
-        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B()); SMO_TRY(adj_C(idx)); }
+        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B(idx)); SMO_TRY(adj_C(idx)); }
         SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0]));
         SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1]));
         SMO_HIP(hipGetLastError());
@@ -721,6 +747,11 @@ public:
         SMO_TRY(reduce_partials(&s));
         *out = s / ((double)g.G * g.G * g.G);
         return SMO_OK;
+    }
+
+    double info(int key) const override {
+        if (key == 0) return (double)ck;
+        return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 
     int snapshot_read(int, int index, double* out) override {
@@ -749,14 +780,14 @@ public:
             case SMO_KD_C2G_A: rc = c2g_A(i0 == 2 ? d_nu : d_G, i0 == 0); break;
             case SMO_KD_C2G_B: rc = c2g_B(p0 ? static_cast<double*>(p0) : d_U); break;
             case SMO_KD_FWD_A: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_A(i0); break;
-            case SMO_KD_FWD_B: rc = fwd_B(); break;
+            case SMO_KD_FWD_B: rc = fwd_B(i0); break;
             case SMO_KD_FWD_C: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_C(i0); if (i0 == N - 1) have_forward = true; break;
             case SMO_KD_ENERGY: if (!step_ok(i0, N) || !out) return SMO_ERR_ARG; return energy(snap(i0), out);
             case SMO_KD_ADJ_INIT:
                 if (!have_forward) { set_error("smo_kdyn_op: adjoint before forward"); return SMO_ERR_STATE; }
                 rc = adj_init(i0); break;
             case SMO_KD_ADJ_A: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_A(i0); break;
-            case SMO_KD_ADJ_B: rc = adj_B(); break;
+            case SMO_KD_ADJ_B: rc = adj_B(i0); break;
             case SMO_KD_ADJ_C: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_C(i0); break;
             case SMO_KD_SYNC: SMO_HIP(hipStreamSynchronize(stream)); break;
             default: set_error("smo_kdyn_op: unknown op %d", op); return SMO_ERR_ARG;

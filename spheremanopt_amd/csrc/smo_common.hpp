@@ -132,6 +132,7 @@ public:
         return SMO_ERR_UNSUPPORTED;
     }
 
+    virtual double info(int key) const { return key == 0 ? 1.0 : 0.0; }
     virtual int kdyn_op(int op, int i0, int i1, void* p0, void* p1, double* out) {
         (void)op; (void)i0; (void)i1; (void)p0; (void)p1; (void)out;
         set_error("smo_kdyn_op: not a KDYN context");

@@ -188,7 +188,7 @@ class SlabKDyn:
                 J += self.dt * self.ops.energy(n)
             self.ops.phase(FWD_A, n)
             self._exchange(self.buf_y, self.buf_x, 1)
-            self.ops.phase(FWD_B)
+            self.ops.phase(FWD_B, n)
             self._exchange(self.buf_x, self.buf_y, 1)
             self.ops.phase(FWD_C, n)
         E = self.ops.energy(self.n_iters)
@@ -205,7 +205,7 @@ class SlabKDyn:
         for _ in range(self.n_iters):
             self.ops.phase(ADJ_A, idx)
             self._exchange(self.buf_y, self.buf_x, 2)
-            self.ops.phase(ADJ_B)
+            self.ops.phase(ADJ_B, idx)
             self._exchange(self.buf_x, self.buf_y, 2)
             self.ops.phase(ADJ_C, idx)
             idx -= 1

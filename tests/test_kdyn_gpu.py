@@ -159,3 +159,27 @@ def test_reference_ic_recipe_with_device_prep():
     # analytic flow variant
     _, _, Ua = kdyn.Generate_IC(N, U_Noise=False)
     assert abs(o.inner(Ua, Ua) - 1) < 1e-12
+
+
+def test_y_side_stack_is_bit_identical(monkeypatch):
+    """The forward solve keeps the y-pass output of every state in HBM so the adjoint can skip two kernels per step; turning
+    that off (SMO_KD_TYSTACK=0) must give exactly the same numbers, for both adjoint types (Continuous needs state N, which
+    the forward solve never transforms, so that one snapshot is always recomputed)."""
+    N, n = 32, 5
+    B, U = _fields(3 * N // 2, dirty=True)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SMO_KD_TYSTACK", flag)
+        dom = kdyn.KDynDomain(N)
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        for adj in ("Discrete", "Continuous"):
+            args = [dom, 1., 1e-3, n, n, buf, "Integrated", adj]
+            J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+            g = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+            res[(flag, adj)] = (J, g)
+        ctx = dom.context(1., 1e-3, n, "Integrated")
+        assert (ctx.get(1) > 0) == (flag == "1") and ctx.get(0) == 1
+        dom.drop_contexts()
+    for adj in ("Discrete", "Continuous"):
+        a, b = res[("1", adj)], res[("0", adj)]
+        assert a[0] == b[0] and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
