@@ -209,9 +209,16 @@ def bench_kdyn(a, torch, rank, world):
     ck = int(ctx.get(0))
     Bd, Ud = torch.from_numpy(B).cuda(), torch.from_numpy(U).cuda()
     gB, gU = torch.empty_like(Bd), torch.empty_like(Ud)
-    for _ in range(warm):
-        ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
+    # warm-up passes time EVERY kernel class (breakdown + which kernel dominates); the timed region then records HIP events only
+    # around the dominant kernel's launches so that the instrumentation does not slow the other 14 launches of a step pair
     ctx.timing_enable(True)
+    for _ in range(max(warm, 1)):
+        ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
+    tim = ctx.timing()
+    tot_ms = sum(t["total_ms"] for t in tim)
+    dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"])
+    share = tim[dom_i]["total_ms"] / tot_ms
+    ctx.timing_enable(only=dom_i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -222,13 +229,11 @@ def bench_kdyn(a, torch, rank, world):
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
-    tim = ctx.timing()
-    tot_ms = sum(t["total_ms"] for t in tim)
-    dom_k = max(tim, key=lambda t: t["total_ms"])
+    dom_k = ctx.timing()[dom_i]
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
             "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
-            "kernel_time_share": dom_k["total_ms"] / tot_ms,
+            "kernel_time_share": share,
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1),
                              "GBps": (t["bytes_per_launch"] / (t["total_ms"] / max(t["launches"], 1) * 1e-3) / 1e9) if t["launches"] else 0.0}
                             for t in tim],

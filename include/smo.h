@@ -138,7 +138,8 @@ int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double
 int smo_set_stream(smo_ctx* ctx, void* hip_stream);
 
 /* HIP-event timing of the kernels launched by the context (measured on the context's stream).
- * smo_timing_enable(ctx, 1) resets the accumulators; smo_timing_get returns, for kernel class `k`
+ * smo_timing_enable(ctx, on) resets the accumulators; on = 0 off, 1 every class, 2 + k only class k (two event records per
+ * launch cost ~2 us on the GPU, so the benchmark times only the dominant class inside its timed region); smo_timing_get returns, for kernel class `k`
  * (0 <= k < smo_timing_classes), its name, number of launches, total milliseconds and the ALGORITHMIC bytes
  * one launch moves (DESIGN.md section "kernels"), so  achieved GB/s = bytes * launches / ms / 1e6. */
 int         smo_timing_enable(smo_ctx* ctx, int on);

@@ -216,8 +216,9 @@ class Context:
         _check(lib().smo_get(self._h, int(key), C.byref(v)))
         return v.value
 
-    def timing_enable(self, on=True):
-        _check(lib().smo_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True, only=None):
+        """on=False: off; on=True: every kernel class; only=k: just class k (index into timing())."""
+        _check(lib().smo_timing_enable(self._h, (2 + int(only)) if only is not None else (1 if on else 0)))
 
     def timing(self):
         res = []

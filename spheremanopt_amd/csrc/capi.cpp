@@ -178,6 +178,7 @@ int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
     ctx->impl->timing.reset();
     ctx->impl->timing.on = (on != 0);
+    ctx->impl->timing.only = (on >= 2) ? on - 2 : -1;
     return SMO_OK;
 }
 int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->timing.cls.size() : 0; }

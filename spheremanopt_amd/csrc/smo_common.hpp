@@ -84,6 +84,7 @@ struct TimingClass {
 class Timing {
 public:
     bool on = false;
+    int only = -1;                    // -1: time every class; k >= 0: only class k (keeps the event overhead out of the other launches)
     std::vector<TimingClass> cls;
     int add_class(const char* name, double bytes) { cls.push_back({name, bytes, 0, 0.0}); return (int)cls.size() - 1; }
     void reset();
@@ -100,8 +101,11 @@ private:
 
 struct ScopedTimer {
     Timing& t; int k; hipStream_t s;
-    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_) { if (t.on) t.begin(k, s); }
-    ~ScopedTimer() { if (t.on) t.end(k, s); }
+    bool active;
+    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && (t_.only < 0 || t_.only == k_)) {
+        if (active) t.begin(k, s);
+    }
+    ~ScopedTimer() { if (active) t.end(k, s); }
 };
 
 // ---------------------------------------------------------------------------------------------------------
