@@ -120,33 +120,34 @@ def FWD_Solve_IVP_Prep(Bx0, Ux0, domain, Rm, dt, N_ITERS):
     return [_coeff_to_grid_host(domain, C[i]) for i in range(3)]
 
 
+def _analytic_flow(dom):
+    """0.5/sqrt(3) * (sin y cos z, sin z cos x, sin x cos y)  (FWD_Solve_KDyn.py:258-260), on the 3/2 grid."""
+    s = dom.interval[0] + (dom.interval[1] - dom.interval[0]) * np.arange(dom.G) / dom.G
+    x, y, z = np.meshgrid(s, s, s, indexing='ij')
+    return np.stack([np.sin(y) * np.cos(z), np.sin(z) * np.cos(x), np.sin(x) * np.cos(y)]) * (0.5 / np.sqrt(3.))
+
+
+def _normalised(v, val):
+    return (v * np.sqrt(val / np.mean((v * v).sum(0)))).reshape(-1)
+
+
 def Generate_IC(Npts, X=(0., 2. * np.pi), M_0=1.0, U_Noise=False, seeds=(1, 2), device=0, reference_recipe=False, Rm=1.0, dt=1e-3):
     """Domain + (B0, U) with <B0,B0> = M_0, <U,U> = 1.
-    reference_recipe=False: the synthetic fields of SURVEY.md 8d (seeded, band-limited, solenoidal, mean-free) used by the tests
-    and the benchmark.  reference_recipe=True: FWD_Solve_KDyn.py:183-317 — B = curl-type field of seed-42 noise smoothed by 101
-    device steps; U = that same noise field normalised (U_Noise=True) or the analytic flow of :258-260; IC generation itself runs on
-    the host (NumPy), only the smoothing solve uses the device."""
+
+    reference_recipe=False (tests, benchmark): the synthetic fields of SURVEY.md 8d — seeded, band-limited, solenoidal, mean-free.
+    reference_recipe=True: FWD_Solve_KDyn.py:183-317 — B = curl-type field of seed-42 noise smoothed by 101 DEVICE steps of the
+    forward solver; U = that same noise field (U_Noise=True) or the analytic flow of :258-260.  The field construction itself
+    runs on the host (NumPy): it is not on the hot path."""
     dom = KDynDomain(Npts, X, device=device)
-    G = dom.G
-
-    def normalise(v, val):
-        return v * np.sqrt(val / np.mean((v * v).sum(0)))
-
-    if not reference_recipe:
-        B = synthetic_field(G, seeds[0], M_0)
-        if U_Noise:
-            return dom, B, synthetic_field(G, seeds[1], 1.0)
-    if (not U_Noise) or reference_recipe:
-        if U_Noise:
-            U = normalise(_curl_noise(dom, 42), 1.0)
-        else:
-            s = X[0] + (X[1] - X[0]) * np.arange(G) / G
-            x, y, z = np.meshgrid(s, s, s, indexing='ij')
-            U = normalise(np.stack([np.sin(y) * np.cos(z), np.sin(z) * np.cos(x), np.sin(x) * np.cos(y)]) * (0.5 / np.sqrt(3.)), 1.0)
-        U = U.reshape(-1)
+    if U_Noise:
+        U = _normalised(_curl_noise(dom, 42), 1.0) if reference_recipe else synthetic_field(dom.G, seeds[1], 1.0)
+    else:
+        U = _normalised(_analytic_flow(dom), 1.0)
     if reference_recipe:
-        B = _curl_noise(dom, 42).reshape(-1)
-        B = normalise(np.stack(FWD_Solve_IVP_Prep(B, U, dom, Rm, dt, 100)), M_0).reshape(-1)
+        raw = _curl_noise(dom, 42).reshape(-1)
+        B = _normalised(np.stack(FWD_Solve_IVP_Prep(raw, U, dom, Rm, dt, 100)), M_0)
+    else:
+        B = synthetic_field(dom.G, seeds[0], M_0)
     return dom, B, U
 
 

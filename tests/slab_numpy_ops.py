@@ -85,12 +85,11 @@ class NumpyOps:
             if i0 == 0:
                 self.stack[0] = c
             else:
-                self.scratch = c
+                self.scratch, self.Gh = c, None        # a new forward solve starts: the device reuses G^'s memory as scratch
         elif code == C2G_A:
-            src = {0: lambda: self.dt * o.alpha * self.Gh, 1: lambda: self.Gh if self.Gh is not None else self.scratch,
+            # source 1 is "the G^/scratch array": scratch (U^) during the forward set-up, G^ once the adjoint has started
+            src = {0: lambda: self.dt * o.alpha * self.Gh, 1: lambda: self.scratch if self.Gh is None else self.Gh,
                    2: lambda: self.nu}[i0]()
-            if i0 == 1 and self._use_scratch:
-                src = self.scratch
             self._put_y(self._zy_inverse(src), 0, 1)
         elif code == C2G_B:
             g = self._x_to_grid(self._get_x(0, 1))
@@ -115,7 +114,6 @@ class NumpyOps:
                 self.Gh = o.project(-2. * BN) / scale
                 self.Gh[:, o.zero] = 0.
             self.nu = np.zeros_like(self.Gh)
-            self._use_scratch = False
         elif code == ADJ_A:
             self._put_y(self._zy_inverse(o.curl(self.Gh)), 0, 2)
             self._put_y(self._zy_inverse(self.stack[i0]), 1, 2)
@@ -134,8 +132,6 @@ class NumpyOps:
             self.nu = nu_new
         else:
             raise ValueError(code)
-
-    _use_scratch = True       # before the first adjoint, C2G_A(1) means "scratch" (U^)
 
     def energy(self, n):
         w = np.where(self.o.K[0] == 0, 1., 2.)
