@@ -1,7 +1,7 @@
 // LDS-staged Stockham autosort FFT for gfx950, complex128.
 //
 // A length-L transform is a chain of decimation-in-frequency Stockham stages of radix 4, then 2, then 3
-// (L = 4^a 2^b 3^c, b,c in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..384).  Stage invariant n*s == L:
+// (L = 4^a 2^b 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..384 incl. 36 = 4*3*3 for Npts = 24).  Stage invariant n*s == L:
 //     y[q + s*(R*p + j)] = w_n^{p*j} * sum_k x[q + s*(p + k*n/R)] * w_R^{j*k},  0 <= p < n/R, 0 <= q < s
 // so (i) the R inputs of consecutive butterflies are consecutive 16-byte elements (conflict-free ds_read_b128 /
 // coalesced global loads) and (ii) in the last stage p == 0: no twiddles, outputs of consecutive butterflies
@@ -19,7 +19,7 @@ constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + s
 constexpr bool fft_length_ok(int n) {
     while (n % 4 == 0) n /= 4;
     if (n % 2 == 0) n /= 2;
-    if (n % 3 == 0) n /= 3;
+    while (n % 3 == 0) n /= 3;
     return n == 1;
 }
 

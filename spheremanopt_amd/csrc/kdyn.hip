@@ -465,8 +465,8 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        if (N % 2 != 0 || !(N == 8 || N == 16 || N == 32 || N == 64 || N == 128 || N == 256)) {
-            set_error("KDYN: npts must be one of 8,16,32,64,128,256 (got %d)", N);
+        if (!(N == 8 || N == 16 || N == 24 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128 || N == 256)) {
+            set_error("KDYN: npts must be one of 8,16,24,32,48,64,96,128,256 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
         if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
@@ -537,6 +537,9 @@ public:
         switch (g.G) {
             case 12: return f(std::integral_constant<int, 12>());
             case 24: return f(std::integral_constant<int, 24>());
+            case 36: return f(std::integral_constant<int, 36>());      // Npts = 24, the reference script's default
+            case 72: return f(std::integral_constant<int, 72>());
+            case 144: return f(std::integral_constant<int, 144>());
             case 48: return f(std::integral_constant<int, 48>());
             case 96: return f(std::integral_constant<int, 96>());
             case 192: return f(std::integral_constant<int, 192>());
