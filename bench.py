@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=None, help="override N_ITERS (the result is then flagged as reduced)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short SH23 / SHB23 lines appended to the default run")
     ap.add_argument("--replicas", action="store_true", help="N>1: run N independent gradients instead of the slab decomposition")
     return ap.parse_args()
 
@@ -292,6 +293,15 @@ def main():
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
     else:
         raise SystemExit("workload %s not built yet" % wl)
+    secondary = None
+    if world == 1 and a.workload is None and not a.no_secondary:
+        # the two latency-bound 1-D configs of BASELINE.json (configs[1], configs[2]) ride along as secondary lines
+        secondary = []
+        for fn, kw in ((bench_sh23, dict(steps=50, warmup=5)), (bench_shb23, dict(steps=10, warmup=2))):
+            b = argparse.Namespace(**{**vars(a), "npts": None, "iters": None, "batch": 1, "no_cpu_baseline": True, **kw})
+            st, wm, e2, units, rf, cf, _ = fn(b, torch, rank, world)
+            secondary.append({"workload": cf["workload"], "value": st * units / e2, "unit": "gradient evals/s", "ms_per_step": 1e3 * e2 / st,
+                              "us_per_time_step": rf["avg_launch_ms"] * 1e3 / cf["n_iters"], "steps": st, "warmup": wm})
     if world > 1:
         t = torch.tensor([el], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -302,6 +312,8 @@ def main():
                "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
                "roofline": roof, "cpu_baseline": cpu}
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
