@@ -348,10 +348,10 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     }
 }
 
-// One tile per workgroup.  PAIRED: the tile is narrower than a 128-byte line of the spectra (T = 4 complex), so tiles 2k and
-// 2k+1 are given to workgroups b and b+8, which the dispatcher places on the same XCD at about the same time: the second
-// half of every line is then served by that XCD's L2 instead of being fetched from HBM twice (speed only, never correctness).
-template <int L, int MODE, int T, int NT, bool PAIRED = false>
+// One tile per workgroup.  PAIRED = P > 1: the tile is narrower than a 128-byte line of the spectra (T = 8/P complex), so the P
+// tiles of a line are given to workgroups b, b+8, ..., which the dispatcher places on the same XCD at about the same time: the
+// rest of every line is then served by that XCD's L2 instead of being fetched from HBM again (speed only, never correctness).
+template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = tiles per 128-byte line of the spectra (0/1: no remapping)
 __global__ __launch_bounds__(NT) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(NT) void kd_x_pass(XSpec sp, const double* __restri
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
     __syncthreads();
     size_t tile = blockIdx.x;
-    if (PAIRED && blockIdx.x < (gridDim.x / 16) * 16) {
-        const unsigned q = blockIdx.x / 16, r = blockIdx.x % 16;
-        tile = (size_t)q * 16 + 2 * (r % 8) + r / 8;
+    if (PAIRED > 1 && blockIdx.x < (gridDim.x / (8 * PAIRED)) * (8 * PAIRED)) {
+        const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);
+        tile = (size_t)q * (8 * PAIRED) + PAIRED * (r % 8) + r / 8;
     }
     x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, tw, tile * T, tid);
 }
@@ -556,7 +556,7 @@ public:
         static constexpr int ZA_NBT = 2 / H, ZA_NT = 192;      // adjoint update: row triples x 2 fields
         static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
         static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: (y,z) points per workgroup (12 / 6 FFTs); 128-B runs at G=192
-        static constexpr int XTA = 4, XANT = 192 * H;          // adjoint x pass: 12 FFTs of both field groups; 64-B runs, tiles paired per XCD
+        static constexpr int XTA = 4 / H, XANT = 192;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
 
@@ -605,8 +605,8 @@ public:
             switch (mode) {
                 case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, (S::XT < 8)>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, true>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
             }
             return SMO_OK;
         });
