@@ -370,12 +370,17 @@ def LS_wolfe_multiple(f, myfprime, inner_prod, M_0, X_k, g_k, d_k, old_fval=None
 # ----------------------------------------------------------------------------------
 
 def _dump_progress(R):
-    """Rank-0 rewrite of DAL_PROGRESS.h5; every failure is swallowed (Sphere_Grad_Descent.py:821-829)."""
+    """Rank-0 rewrite of DAL_PROGRESS.h5 with every field of the progress record; every failure is swallowed
+    (Sphere_Grad_Descent.py:821-829).  Without h5py / mpi4py (both optional here) the same keys go to DAL_PROGRESS.npz."""
     try:
-        if _MPI.COMM_WORLD.rank == 0:
+        if _MPI is not None and _MPI.COMM_WORLD.rank != 0:
+            return
+        if _h5py is not None:
             with _h5py.File('DAL_PROGRESS.h5', 'w') as fh:
                 for key, val in vars(R).items():
                     fh.create_dataset(key, data=val)
+        else:
+            np.savez('DAL_PROGRESS.npz', **{key: np.asarray(val) for key, val in vars(R).items()})
     except Exception:
         pass
 

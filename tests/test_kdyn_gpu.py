@@ -29,11 +29,12 @@ def _fields(G, dirty=False):
     return B, U
 
 
-@pytest.mark.parametrize("N,n,dt,dirty", [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True)])
+@pytest.mark.parametrize("N,n,dt,dirty", [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True),
+                                          (96, 1, 1e-3, False)])
 @pytest.mark.parametrize("cost", ["Final", "Integrated"])
 @pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
 def test_forward_adjoint_vs_oracle(N, n, dt, dirty, cost, adj):
-    if N == 64 and (cost, adj) != ("Final", "Discrete"):
+    if N >= 64 and (cost, adj) != ("Final", "Discrete"):
         pytest.skip("large case only for the default configuration")
     dom = kdyn.KDynDomain(N)
     B, U = _fields(dom.G, dirty)

@@ -48,6 +48,10 @@ def test_pca_traces_match_reference(DIM, in_tmp_cwd):
         assert np.array_equal(X_opt[0], gold[tag + "_xopt"]), tag
         assert calls == list(gold[tag + "_calls"]), tag
     assert os.path.exists("optimize_result.txt")
+    if os.path.exists("DAL_PROGRESS.npz"):          # restart file (h5py absent: same keys as the reference's DAL_PROGRESS.h5)
+        prog = np.load("DAL_PROGRESS.npz")
+        assert int(prog["Iterations"]) == len(FUN) and np.array_equal(prog["Function_Value"], np.asarray(FUN))
+        assert np.array_equal(prog["X_opt"][0], X_opt[0])
 
     if DIM == 512:   # config 1 acceptance: CG converges to the top eigenpair
         lam, vec = np.linalg.eigh(M)
