@@ -166,8 +166,17 @@ def bench_kdyn_slab(a, torch, rank, world):
     steps = a.steps if a.steps is not None else 2
     warm = a.warmup if a.warmup is not None else 1
     G = 3 * N // 2
+    Bfull, Ufull = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    # integrity check of the decomposition: rank 0 first evaluates J on its own GPU with the single-GPU path (same kernels, no
+    # exchange); every rank's slab result must agree with it to 1e-9 relative
+    J_single = torch.zeros(1, dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
+    if rank == 0:
+        dom1 = kdyn.KDynDomain(N, device=torch.cuda.current_device())
+        J_single[0] = dom1.context(Rm, dt, n_iters, "Final").forward([Bfull, Ufull])
+        dom1.drop_contexts()
+    torch.distributed.broadcast(J_single, 0)
     s = SlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device())
-    Bl = s.local_slab(kdyn.synthetic_field(G, 1)); Ul = s.local_slab(kdyn.synthetic_field(G, 2))
+    Bl = s.local_slab(Bfull); Ul = s.local_slab(Ufull)
     out = [torch.empty_like(Bl), torch.empty_like(Ul)]
     for _ in range(warm):
         s.forward([Bl, Ul]); s.adjoint("Discrete", out)
@@ -192,6 +201,8 @@ def bench_kdyn_slab(a, torch, rank, world):
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
            "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ops.ctx.stack_bytes / 1e9,
+           "slab_J_matches_single_gpu": bool(abs(J - float(J_single.item())) <= 1e-9 * abs(float(J_single.item()))),
+           "J_single_gpu": float(J_single.item()),
            "parallelism": "slab x%d (kx / y decomposition, RCCL all-to-all, %d field-group exchanges per step pair)" % (world, 4),
            "exchange_MB_per_gpu_per_step_pair": 6 * s.elems * 16 / 1e6}
     return steps, warm, el, 1, roof, cfg, None, "strong"
@@ -284,6 +295,8 @@ def main():
     elif wl == "kdyn" and world > 1 and not a.replicas:
         try:
             steps, warm, el, per_step_units, roof, cfg, cpu, scaling = bench_kdyn_slab(a, torch, rank, world)
+            if not cfg["slab_J_matches_single_gpu"]:
+                raise RuntimeError("slab-decomposed J %r differs from the single-GPU J %r" % (cfg["J"], cfg["J_single_gpu"]))
             per_step_units = 1.0 / world          # ONE gradient is shared by all ranks (value = steps / time)
         except Exception as e:                   # keep the contract (one JSON line) even if the slab path fails on this node
             sys.stderr.write("rank %d: slab path failed (%r); falling back to independent replicas\n" % (rank, e))
@@ -304,6 +317,7 @@ def main():
                               "us_per_time_step": rf["avg_launch_ms"] * 1e3 / cf["n_iters"], "steps": st, "warmup": wm})
     if world > 1:
         t = torch.tensor([el], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
+        scaling = scaling if "slab" in cfg.get("parallelism", "") else "weak"
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
     if rank == 0:
