@@ -49,6 +49,7 @@ enum { SMO_OK = 0, SMO_ERR_ARG = 1, SMO_ERR_NO_DEVICE = 2, SMO_ERR_HIP = 3, SMO_
 
 enum { SMO_SH23 = 1, SMO_SHB23 = 2, SMO_KDYN = 3 };            /* smo_config.kind */
 enum { SMO_COST_FINAL = 0, SMO_COST_INTEGRATED = 1 };           /* smo_config.cost (KDYN) */
+enum { SMO_SHB_DISCRETE = 0, SMO_SHB_CONTINUOUS = 1 };          /* smo_config.cost (SHB23): formulation, FWD_Solve_SHB23.py:213-217 */
 enum { SMO_ADJ_DISCRETE = 0, SMO_ADJ_CONTINUOUS = 1 };          /* `adjoint_type` argument */
 
 typedef struct smo_config {
@@ -58,7 +59,9 @@ typedef struct smo_config {
     double dt;          /* time step */
     int    n_iters;     /* N_ITERS (the forward solve executes N_ITERS+1 steps for SH23/KDYN, like the reference) */
     double param;       /* SH23/SHB23: a (-0.3 / -0.1);  KDYN: Rm */
-    int    cost;        /* KDYN: SMO_COST_FINAL | SMO_COST_INTEGRATED */
+    int    cost;        /* KDYN: SMO_COST_FINAL | SMO_COST_INTEGRATED.  SHB23: SMO_SHB_DISCRETE (npts grid values = npts modes; snapshots
+                           are grid states) | SMO_SHB_CONTINUOUS (npts modes, vectors hold the 2*npts values of the scale-2 grid,
+                           snapshots are the npts T-coefficients; smo_adjoint must then be called with adjoint_type Continuous) */
     int    batch;       /* independent problems per call (>=1; KDYN: 1) */
     int    device;      /* HIP device ordinal */
     /* slab decomposition of the 3-D case (one process per GPU; the exchange itself is done by the host layer):  */

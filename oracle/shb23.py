@@ -162,3 +162,74 @@ def synthetic_ic(oracle, seed, M0, prep_steps=100):
         c = oracle.S @ (oracle.nl(c) + c / oracle.dt)
     g = transformInverse(c)
     return g * np.sqrt(M0 / oracle.inner(g, g))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# "Continuous" path (Adjoint_type = "Continuous", FWD_Solve_SHB23.py:322-355, 398-523, 685-794, 156-187): a Dedalus IVP
+# with SBDF1 on N Chebyshev modes and dealias = 2 — PARITY UNPINNED like the discrete tau solve (same Dedalus internals).
+#   * state = N T-coefficients; products on the scale-2 Gauss grid (2N points), transformed back and truncated to N modes
+#   * every step: (M/dt + L) X1 = M X0/dt + F  ->  c1 = S (c0/dt + F^),  S = the same tau operator, built for N modes
+#   * J = dt * sum_{n=0}^{N_ITERS} (1/Lz) integ(u_n^2);  integ acts on the truncated coefficients:
+#         integ(f) = (Lz/2) * sum_{k even} f_k * 2/(1-k^2)
+#     <x,y> (Inner_Prod_Cnts) = (1/Lz) integ(x*y) with x, y given on the scale-2 grid (no truncation of x, y themselves)
+#   * continuous adjoint: q(0) = 0; q1 = S (q0/dt + trunc T[(4 uf - 3 uf^2) q - 2 uf]), uf from the coefficient snapshots
+#     N, N-1, ..., 1; gradient = q on the scale-2 grid (no "undo LHS").
+# Flat vectors live on the scale-2 grid (2N values); the snapshot stack holds coefficients (N, N_ITERS+1).
+# ---------------------------------------------------------------------------------------------------------------
+class SHB23CntsOracle:
+    def __init__(self, Npts=256, interval=(-20., 20.), dt=1e-2, N_ITERS=2000, a=-0.1):
+        self.N, self.G = int(Npts), 2 * int(Npts)
+        self.dt, self.N_ITERS, self.a = float(dt), int(N_ITERS), a
+        self.Lz = float(interval[1] - interval[0])
+        self.S = tau_operator(self.N, self.dt, a, interval)
+        k = np.arange(self.N)
+        self.w_int = np.where(k % 2 == 0, 2. / np.where(k == 1, 1., 1. - k.astype(float) ** 2), 0.) * (self.Lz / 2.)
+        self.stack = None
+
+    def to_grid(self, c):
+        p = np.zeros(self.G); p[:self.N] = c
+        return transformInverse(p)
+
+    def to_coeff(self, g):
+        return transform(g)[:self.N]
+
+    def integ_mean(self, g):
+        return float(np.dot(self.w_int, self.to_coeff(g)) / self.Lz)
+
+    def inner(self, x, y):
+        return self.integ_mean(np.asarray(x) * np.asarray(y))
+
+    def forward(self, X):
+        dt, n_it = self.dt, self.N_ITERS
+        self.stack = np.zeros((self.N, n_it + 1))
+        c = self.to_coeff(np.asarray(X[0], dtype=float))            # the state is truncated by the solver (A.0-4)
+        J = 0.
+        for n in range(n_it + 1):
+            self.stack[:, n] = c
+            g = self.to_grid(c)
+            J += dt * self.integ_mean(g * g)
+            c = self.S @ (c / dt + self.to_coeff(2. * g ** 2 - g ** 3))
+        return -J
+
+    def adjoint(self, X=None):
+        dt, n_it = self.dt, self.N_ITERS
+        q = np.zeros(self.N)
+        idx = n_it
+        for _ in range(n_it):
+            uf = self.to_grid(self.stack[:, idx]); idx -= 1
+            qg = self.to_grid(q)
+            q = self.S @ (q / dt + self.to_coeff((4. * uf - 3. * uf ** 2) * qg - 2. * uf))
+        return [self.to_grid(q)]
+
+
+def synthetic_ic_cnts(oracle, seed, M0, prep_steps=100):
+    """Noise on the scale-2 grid, upper half of the N modes removed (frac = 0.5, SHB:258), smoothed by `prep_steps`+1 steps,
+    scaled to <X,X> = M0 (SHB:195-268 with Adjoint_type = "Continuous")."""
+    N = oracle.N
+    c = oracle.to_coeff(np.random.RandomState(seed).standard_normal(oracle.G))
+    c[np.linspace(0, 1, N, endpoint=False) > 0.5] = 0.
+    for _ in range(prep_steps + 1):
+        g = oracle.to_grid(c)
+        c = oracle.S @ (c / oracle.dt + oracle.to_coeff(2. * g ** 2 - g ** 3))
+    g = oracle.to_grid(c)
+    return g * np.sqrt(M0 / oracle.inner(g, g))

@@ -164,20 +164,22 @@ template <int NH> __device__ void dct3(DctWork<NH>& w, const double* x, double* 
 
 // out[n] = sum_j M[j][n] v[j]   (M row j contiguous in n: coalesced 16-byte loads; v, out, part in LDS)
 __device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
-    const int npairs = N >> 1, ngrp = NT / npairs, cols = N / ngrp;
+    const int npairs = N >> 1, ngrp = (NT / npairs < N) ? NT / npairs : N, cols = N / ngrp;    // N = 32: 32 groups, half the block idles
     const int np = tid % npairs, jg = tid / npairs;
     const double2* M2 = reinterpret_cast<const double2*>(M);
-    double a0 = 0.0, a1 = 0.0;
-    const int j0 = jg * cols;
+    if (jg < ngrp) {
+        double a0 = 0.0, a1 = 0.0;
+        const int j0 = jg * cols;
 #pragma unroll 8
-    for (int j = j0; j < j0 + cols; ++j) {
-        const double2 m = M2[(size_t)j * npairs + np];
-        const double vj = v[j];
-        a0 += m.x * vj;
-        a1 += m.y * vj;
+        for (int j = j0; j < j0 + cols; ++j) {
+            const double2 m = M2[(size_t)j * npairs + np];
+            const double vj = v[j];
+            a0 += m.x * vj;
+            a1 += m.y * vj;
+        }
+        part[jg * N + 2 * np] = a0;
+        part[jg * N + 2 * np + 1] = a1;
     }
-    part[jg * N + 2 * np] = a0;
-    part[jg * N + 2 * np + 1] = a1;
     __syncthreads();
     for (int n = tid; n < N; n += NT) {
         double s = 0.0;
@@ -209,7 +211,7 @@ struct Cluster {
 };
 
 // y (LDS, full length N) <- M x with M row-sliced over the cluster; returns false on timeout (uniform over the workgroup)
-__device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double* y, int N, int tid) {
+__device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double* y, int N /* operator dimension */, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     double* dst = c.buf + (size_t)(c.step & 1) * N + (size_t)c.k * c.R;
     for (int row = wave; row < c.R; row += NT / 64) {
@@ -273,19 +275,22 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
                                                          const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
                                                          const cplx* __restrict__ tw4_g, double dt, double inv_Lz, int n_iters,
                                                          int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
-                                                         unsigned* cl_err) {
+                                                         unsigned* cl_err, int Nc, int cnts) {
+    // N = grid / DCT length; Nc = number of Chebyshev modes the operator acts on (Nc = N for the "Discrete" path; Nc = N/2 for the
+    // "Continuous" path: dealias-2 grid, coefficients beyond Nc stay zero, the snapshot stack holds coefficients instead of grid states)
     constexpr int N = 2 * NH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
     const int tid = threadIdx.x;
     const size_t prob = blockIdx.x / KC;
+    const int NS = cnts ? Nc : N;                    // doubles per snapshot
     X += prob * N;
-    stack += prob * (size_t)(n_iters + 1) * N;
-    Cluster cl{KC, (int)(blockIdx.x % KC), N / KC, nullptr, cl_buf + prob * 2 * N, cl_cnt + prob, cl_err, 0u, &s.flag};
+    stack += prob * (size_t)(n_iters + 1) * NS;
+    Cluster cl{KC, (int)(blockIdx.x % KC), Nc / KC, nullptr, cl_buf + prob * 2 * Nc, cl_cnt + prob, cl_err, 0u, &s.flag};
     if (KC > 1) {                                    // my rows of S stay in LDS for the whole solve
         double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
-        const double* src = Mrow + (size_t)cl.k * cl.R * N;
-        for (int i = tid; i < cl.R * N; i += NT) ms[i] = src[i];
+        const double* src = Mrow + (size_t)cl.k * cl.R * Nc;
+        for (int i = tid; i < cl.R * Nc; i += NT) ms[i] = src[i];
         cl.Ms = ms;
     }
     const bool writer = (cl.k == 0);
@@ -294,18 +299,21 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
     __syncthreads();
     // c = T X : dct2 / N, c[0] *= 1/2, odd modes * -1
     dct2(s.w, s.t, s.c, tid);
-    for (int k = tid; k < N; k += NT) s.c[k] *= ((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N;
+    for (int k = tid; k < N; k += NT) s.c[k] = (k < Nc) ? s.c[k] * (((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N) : 0.0;
     __syncthreads();
     double acc = 0.0;
     const double inv_dt = 1.0 / dt;
     for (int it = 0; it <= n_iters; ++it) {
         // g = T^-1 c : dct3 of (c0, s_k c_k / 2)
-        for (int k = tid; k < N; k += NT) s.t[k] = (k == 0) ? s.c[0] : ((k & 1) ? -0.5 : 0.5) * s.c[k];
+        for (int k = tid; k < N; k += NT) {
+            s.t[k] = (k == 0) ? s.c[0] : ((k & 1) ? -0.5 : 0.5) * s.c[k];
+            if (cnts && writer && k < Nc) stack[(size_t)it * NS + k] = s.c[k];
+        }
         __syncthreads();
         dct3(s.w, s.t, s.g, tid);
         for (int i = tid; i < N; i += NT) {
             const double gi = s.g[i];
-            if (writer) stack[(size_t)it * N + i] = gi;
+            if (!cnts && writer) stack[(size_t)it * NS + i] = gi;
             acc += s.W[i] * gi * gi;
             s.t[i] = gi * gi * (2.0 - gi);            // 2 g^2 - g^3
         }
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
             s.r[k] = h + s.c[k] * inv_dt;
         }
         __syncthreads();
-        if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, N, tid)) return; }
-        else gemv_cols(ST, s.r, s.c, s.part, N, tid);  // c = S r
+        if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, Nc, tid)) return; }
+        else gemv_cols(ST, s.r, s.c, s.part, Nc, tid); // c = S r  (entries beyond Nc stay zero)
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) s.red[tid >> 6] = acc;
@@ -381,6 +389,59 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
         for (int i = tid; i < N; i += NT) grad[i] = -(s.g[i] / N) / s.W[i];
 }
 
+// "Continuous" adjoint (FWD_Solve_SHB23.py:685-794): q(0) = 0; N_ITERS times  q^ <- S (q^/dt + trunc T[(4 uf - 3 uf^2) q - 2 uf]) with uf
+// from the coefficient snapshots N, N-1, ..., 1; the gradient is q on the scale-2 grid.  Same tau operator S as the forward solve.
+template <int NH>
+__global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __restrict__ stack, double* __restrict__ grad, const double* __restrict__ ST,
+                                                              const double* __restrict__ W_g, const cplx* __restrict__ tw_g,
+                                                              const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters,
+                                                              int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
+                                                              unsigned* cl_err, int Nc) {
+    constexpr int N = 2 * NH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    const int tid = threadIdx.x;
+    const size_t prob = blockIdx.x / KC;
+    stack += prob * (size_t)(n_iters + 1) * Nc;
+    grad += prob * N;
+    Cluster cl{KC, (int)(blockIdx.x % KC), Nc / KC, nullptr, cl_buf + prob * 2 * Nc, cl_cnt + prob, cl_err, 0u, &s.flag};
+    if (KC > 1) {
+        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
+        const double* src = Mrow + (size_t)cl.k * cl.R * Nc;
+        for (int i = tid; i < cl.R * Nc; i += NT) ms[i] = src[i];
+        cl.Ms = ms;
+    }
+    load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
+    const double inv_dt = 1.0 / dt;
+    auto to_grid = [&](const double* coeff, double* out) {          // T^-1 of a coefficient vector that is zero beyond Nc
+        for (int k = tid; k < N; k += NT) s.t[k] = (k == 0) ? coeff[0] : ((k & 1) ? -0.5 : 0.5) * coeff[k];
+        __syncthreads();
+        dct3(s.w, s.t, out, tid);
+    };
+    for (int k = tid; k < N; k += NT) s.c[k] = 0.0;                 // q^
+    __syncthreads();
+    for (int it = 0; it < n_iters; ++it) {
+        const double* snap = stack + (size_t)(n_iters - it) * Nc;
+        for (int k = tid; k < N; k += NT) s.r[k] = (k < Nc) ? snap[k] : 0.0;
+        __syncthreads();
+        to_grid(s.r, s.g);                                          // uf on the grid
+        to_grid(s.c, s.r);                                          // q  on the grid
+        for (int i = tid; i < N; i += NT) { const double u = s.g[i]; s.t[i] = (4.0 * u - 3.0 * u * u) * s.r[i] - 2.0 * u; }
+        __syncthreads();
+        dct2(s.w, s.t, s.r, tid);
+        for (int k = tid; k < N; k += NT) {
+            const double h = (k < Nc) ? s.r[k] * (((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N) : 0.0;
+            s.r[k] = h + s.c[k] * inv_dt;
+        }
+        __syncthreads();
+        if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, Nc, tid)) return; }
+        else gemv_cols(ST, s.r, s.c, s.part, Nc, tid);
+    }
+    to_grid(s.c, s.g);
+    if (cl.k == 0)
+        for (int i = tid; i < N; i += NT) grad[i] = s.g[i];
+}
+
 // standalone Chebyshev maps of the reference (FWD_Solve_SHB23.py:36-67) for the parity tests against its golden vectors
 template <int NH>
 __global__ __launch_bounds__(NT) void shb_transform_kernel(const double* __restrict__ in, double* __restrict__ out, int which,
@@ -422,7 +483,9 @@ __global__ __launch_bounds__(256) void shb_inner_kernel(const double* __restrict
 class SHB23 : public Context {
 public:
     explicit SHB23(const smo_config& c) { cfg = c; }
-    int N = 0, NH = 0;
+    int N = 0, NH = 0;      // grid / DCT length and its half (complex FFT length)
+    int Nc = 0;             // Chebyshev modes of the operator (= N "Discrete", = N/2 "Continuous")
+    bool cnts = false;      // the reference's Adjoint_type = "Continuous" formulation (smo_config.cost = 1)
     double Lz = 0;
     double *d_S = nullptr, *d_ST = nullptr, *d_W = nullptr, *d_stack = nullptr, *d_out = nullptr;
     cplx *d_tw = nullptr, *d_twN = nullptr, *d_tw4 = nullptr;
@@ -432,28 +495,43 @@ public:
     unsigned *d_clcnt = nullptr, *d_clerr = nullptr;
 
     int init() override {
-        N = cfg.npts;
+        cnts = (cfg.cost == 1);
+        Nc = cfg.npts;
+        N = cnts ? 2 * Nc : Nc;                    // "Continuous": npts modes, dealias 2 => vectors live on the 2*npts Gauss grid
         NH = N / 2;
         if (N < 64 || N > 1024 || (N & (N - 1)) != 0) {
-            set_error("SHB23: npts must be a power of two in [64, 1024], got %d", N);
+            set_error("SHB23: the grid length must be a power of two in [64, 1024], got %d", N);
             return SMO_ERR_UNSUPPORTED;
         }
         Lz = cfg.x1 - cfg.x0;
         n_comp = 1;
         vec_len = (size_t)N;
-        snapshot_doubles = (size_t)N;
-        stack_bytes = (size_t)cfg.batch * (cfg.n_iters + 1) * N * sizeof(double);
+        snapshot_doubles = (size_t)(cnts ? Nc : N);
+        stack_bytes = (size_t)cfg.batch * (cfg.n_iters + 1) * snapshot_doubles * sizeof(double);
         SMO_TRY(base_init());
-        std::vector<double> S, ST((size_t)N * N), z(N), W(N);
-        SMO_TRY(build_tau_operator(N, cfg.dt, cfg.param, cfg.x0, cfg.x1, S));
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) ST[(size_t)j * N + i] = S[(size_t)i * N + j];
+        std::vector<double> S, ST((size_t)Nc * Nc), z(N), W(N);
+        SMO_TRY(build_tau_operator(Nc, cfg.dt, cfg.param, cfg.x0, cfg.x1, S));
+        for (int i = 0; i < Nc; ++i)
+            for (int j = 0; j < Nc; ++j) ST[(size_t)j * Nc + i] = S[(size_t)i * Nc + j];
         // ascending Gauss-Chebyshev grid and the reference's trapezoid-like weights (FWD_Solve_SHB23.py:69-81)
         const double zc = 0.5 * (cfg.x0 + cfg.x1), zh = 0.5 * (cfg.x1 - cfg.x0);
         for (int i = 0; i < N; ++i) z[i] = zc + zh * (-std::cos(M_PI * (i + 0.5) / N));
         W[0] = 0.5 * (z[1] - z[0]);
         W[N - 1] = 0.5 * (z[N - 1] - z[N - 2]);
         for (int i = 1; i < N - 1; ++i) W[i] = 0.5 * (z[i] - z[i - 1]) + 0.5 * (z[i + 1] - z[i]);
+        if (cnts) {
+            // <x,y> = (1/Lz) integ(x*y): the product on the grid is transformed, truncated to Nc modes and integrated exactly,
+            // integ(T_k) = (Lz/2) * 2/(1-k^2) for even k  =>  quadrature weights  W_i = sum_{k<Nc, even} integ(T_k) * T[k][i]
+            for (int i = 0; i < N; ++i) {
+                long double acc = 0.0L;
+                for (int k = 0; k < Nc; k += 2) {
+                    const long double wk = (long double)Lz / (1.0L - (long double)k * k);
+                    const long double tki = (k == 0 ? 0.5L : 1.0L) * 2.0L * cosl(M_PIl * k * (2 * i + 1) / (2.0L * N)) / N;
+                    acc += wk * tki;
+                }
+                W[i] = (double)acc;
+            }
+        }
         std::vector<cplx> twN = twiddles(N), t4 = twiddles(4 * N);
         twN.resize(NH);
         t4.resize(NH + 1);
@@ -463,17 +541,17 @@ public:
         SMO_TRY(pool.upload(&d_tw, twiddles(NH), stream));
         SMO_TRY(pool.upload(&d_twN, twN, stream));
         SMO_TRY(pool.upload(&d_tw4, t4, stream));
-        SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * N));
+        SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * snapshot_doubles));
         SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
         // latency mode: a single problem is spread over KC = N^2/8192 CUs (64 KB of operator rows per CU); SMO_SHB_CLUSTER=0 disables
         const char* env = getenv("SMO_SHB_CLUSTER");
-        if (cfg.batch == 1 && N >= 256 && N <= 512 && !(env && atoi(env) == 0)) KC = N * N / 8192;      // N = 1024 would not fit the LDS
-        SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * N));
+        if (cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) KC = Nc * Nc / 8192;    // N = 1024 would not fit the LDS
+        SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * Nc));
         SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 1));
         d_clerr = d_clcnt + cfg.batch;
         SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
         // algorithmic bytes: stack written/read once + the operator once + the vector
-        const double bytes = cfg.batch * ((double)(cfg.n_iters + 1) * N * 8.0 + N * 8.0) + (double)N * N * 8.0;
+        const double bytes = cfg.batch * ((double)(cfg.n_iters + 1) * snapshot_doubles * 8.0 + N * 8.0) + (double)Nc * Nc * 8.0;
         k_fwd = timing.add_class("shb_forward_kernel", bytes);
         k_adj = timing.add_class("shb_adjoint_kernel", bytes);
         return SMO_OK;
@@ -496,12 +574,12 @@ public:
         SMO_TRY(dispatch([&](auto nh) {
             constexpr int H = decltype(nh)::value;
             auto kern = shb_forward_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(N / KC) * N * sizeof(double) : 0);
+            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
             SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
             ScopedTimer t(timing, k_fwd, stream);
             hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                               1.0 / Lz, cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr);
+                               1.0 / Lz, cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr, Nc, cnts ? 1 : 0);
             return SMO_OK;
         }));
         SMO_HIP(hipGetLastError());
@@ -512,9 +590,25 @@ public:
     }
 
     int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
-        if (adjoint_type != SMO_ADJ_DISCRETE) {
-            set_error("SHB23: only the Discrete adjoint is built (the Continuous path is a 'next' row, SURVEY 8f-5)");
-            return SMO_ERR_UNSUPPORTED;
+        if ((adjoint_type == SMO_ADJ_CONTINUOUS) != cnts) {
+            set_error("SHB23: the %s adjoint belongs to a context created with cost = %d (the two formulations use different grids)",
+                      adjoint_type == SMO_ADJ_CONTINUOUS ? "Continuous" : "Discrete", adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
+            return SMO_ERR_ARG;
+        }
+        if (cnts) {
+            SMO_TRY(dispatch([&](auto nh) {
+                constexpr int H = decltype(nh)::value;
+                auto kern = shb_adjoint_cnts_kernel<H>;
+                const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
+                SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
+                ScopedTimer t(timing, k_adj, stream);
+                hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, d_stack, grad[0], d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                                   cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr, Nc);
+                return SMO_OK;
+            }));
+            SMO_HIP(hipGetLastError());
+            return cluster_check("adjoint");
         }
         SMO_TRY(dispatch([&](auto nh) {
             constexpr int H = decltype(nh)::value;
@@ -569,8 +663,8 @@ public:
     }
 
     int snapshot_read(int b, int index, double* out) override {
-        const double* src = d_stack + ((size_t)b * (cfg.n_iters + 1) + index) * N;
-        SMO_HIP(hipMemcpyAsync(out, src, N * sizeof(double), hipMemcpyDeviceToHost, stream));
+        const double* src = d_stack + ((size_t)b * (cfg.n_iters + 1) + index) * snapshot_doubles;
+        SMO_HIP(hipMemcpyAsync(out, src, snapshot_doubles * sizeof(double), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
         return SMO_OK;
     }

@@ -118,6 +118,23 @@ def test_taylor_shb23():
     assert _slopes_ok(AA), AA
 
 
+def test_shb23_continuous_adjoint_is_first_order_consistent():
+    """The "Continuous" SHB23 gradient (q(T) of the adjoint PDE, SHB:685-794) is not the exact gradient of the discrete cost:
+    its directional derivative approaches the finite-difference one as dt -> 0 (T = 1 fixed)."""
+    err = []
+    for n, dt in ((100, 1e-2), (400, 2.5e-3)):
+        o = shb23.SHB23CntsOracle(64, dt=dt, N_ITERS=n)
+        X = shb23.synthetic_ic_cnts(o, 42, 0.0019); dX = shb23.synthetic_ic_cnts(o, 7, 0.0019)
+        assert abs(o.inner(X, X) - 0.0019) < 1e-15
+        o.forward([X])
+        d = o.inner(o.adjoint([X])[0], dX)
+        fd = (o.forward([X + 1e-5 * dX]) - o.forward([X - 1e-5 * dX])) / 2e-5
+        err.append(abs(d - fd) / abs(fd))
+    assert err[0] < 1e-2 and err[1] < 0.6 * err[0], err
+    # every state satisfies the boundary condition imposed on u itself, u(Lz/2) = 0, i.e. sum_k c_k = 0
+    assert abs(o.stack[:, -1].sum()) < 1e-12
+
+
 def test_kdyn_invariants():
     k = KDynOracle(12, Rm=1., dt=1e-2, N_ITERS=5)
     B = synthetic_field(k.G, 1); U = synthetic_field(k.G, 2)

@@ -87,3 +87,69 @@ def test_batch_and_errors():
         ctx.adjoint(None, "Continuous")
     with pytest.raises(_capi.SmoError):
         _capi.Context(_capi.SMO_SHB23, 48, (-20., 20.), 1e-2, 5, -0.1)
+
+
+# ---- "Continuous" formulation (Npts modes, scale-2 grid vectors; FWD_Solve_SHB23.py:398-523, 685-794) --------------------------
+
+@pytest.mark.parametrize("N,n", [(32, 30), (64, 100), (256, 60), (512, 10)])
+def test_continuous_forward_adjoint_vs_oracle(N, n):
+    from oracle import shb23 as osh
+    o = osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n)
+    X = osh.synthetic_ic_cnts(o, 42, 0.0019)
+    dom = shb23.SHBDomain(N, dealias=2)
+    buf = shb23.GEN_BUFFER(N, dom, n)
+    J = shb23.FWD_Solve_IVP_Cnts([X], dom, buf, n, 1e-2)
+    g = shb23.ADJ_Solve_IVP_Cnts([X], dom, buf, n, 1e-2)
+    Jo = o.forward([X]); go = o.adjoint([X])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert len(g) == 1 and g[0].shape == (2 * N,) and rel(g[0], go[0]) < RTOL, rel(g[0], go[0])
+    for i in (0, 1, -1, -2):
+        assert rel(buf['A_fwd'][:, i], o.stack[:, i]) < 1e-8
+    ip = o.inner(X, go[0])
+    assert abs(shb23.Inner_Prod_Cnts(X, g[0], dom) - ip) <= RTOL * abs(ip)
+    assert abs(shb23.Inner_Prod_Cnts(X, X, dom) - 0.0019) < 1e-12
+
+
+def test_continuous_cluster_and_single_workgroup_agree():
+    """Npts=256 runs the 32-workgroup cluster kernel by default; SMO_SHB_CLUSTER=0 forces the single-workgroup one."""
+    from oracle import shb23 as osh
+    N, n = 256, 40
+    o = osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n)
+    X = osh.synthetic_ic_cnts(o, 3, 0.0019)
+    res = []
+    for mode in ("1", "0"):
+        os.environ["SMO_SHB_CLUSTER"] = mode
+        try:
+            ctx = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=1)
+            res.append((ctx.forward([X]), ctx.adjoint(None, "Continuous")[0]))
+        finally:
+            os.environ.pop("SMO_SHB_CLUSTER")
+    assert abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[1][0])
+    assert rel(res[0][1], res[1][1]) < 1e-10
+
+
+def test_continuous_batch_ic_and_errors():
+    from oracle import shb23 as osh
+    N, n, B = 64, 20, 3
+    o = osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n)
+    Xs = np.stack([osh.synthetic_ic_cnts(o, s, 0.0019) for s in range(B)])
+    dom = shb23.SHBDomain(N, dealias=2)
+    ctx = dom.context(1e-2, n, batch=B)
+    J = ctx.forward([Xs]); g = ctx.adjoint(None, "Continuous")[0].reshape(B, -1)
+    for b in range(B):
+        Jo = o.forward([Xs[b]]); go = o.adjoint([Xs[b]])[0]
+        assert abs(J[b] - Jo) <= RTOL * abs(Jo) and rel(g[b], go) < RTOL
+    with pytest.raises(_capi.SmoError):
+        ctx.adjoint(None, "Discrete")
+    # device IC recipe = the oracle's
+    dom2, X = shb23.Generate_IC_Cnts(N, M_0=0.0019, seed=42)
+    assert rel(X, osh.synthetic_ic_cnts(o, 42, 0.0019)) < 1e-9
+    # the continuous adjoint is only O(dt)-consistent with the discrete cost (the oracle shows 0.6 % at dt = 0.01, T = 1): compare the
+    # directional derivative with a central difference of the device forward solve instead of demanding Taylor slope 2
+    _, dX = shb23.Generate_IC_Cnts(N, M_0=0.0019, seed=7)
+    buf = shb23.GEN_BUFFER(N, dom2, 100)
+    shb23.FWD_Solve_IVP_Cnts([X], dom2, buf, 100)
+    d = shb23.Inner_Prod_Cnts(shb23.ADJ_Solve_IVP_Cnts([X], dom2, buf, 100)[0], dX, dom2)
+    e = 1e-5
+    fd = (shb23.FWD_Solve_IVP_Cnts([X + e * dX], dom2, buf, 100) - shb23.FWD_Solve_IVP_Cnts([X - e * dX], dom2, buf, 100)) / (2 * e)
+    assert abs(d - fd) < 1e-2 * abs(fd), (d, fd)
