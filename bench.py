@@ -203,8 +203,10 @@ def bench_kdyn_slab(a, torch, rank, world):
            "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ops.ctx.stack_bytes / 1e9,
            "slab_J_matches_single_gpu": bool(abs(J - float(J_single.item())) <= 1e-9 * abs(float(J_single.item()))),
            "J_single_gpu": float(J_single.item()),
-           "parallelism": "slab x%d (kx / y decomposition, RCCL all-to-all, %d field-group exchanges per step pair)" % (world, 4),
-           "exchange_MB_per_gpu_per_step_pair": 6 * s.elems * 16 / 1e6}
+           "parallelism": "slab x%d (kx / z decomposition, RCCL all-to-all between the z and y passes, %d field-group exchanges per "
+                          "step pair)" % (world, 4 + s.adj_groups),
+           "exchange_MB_sent_per_gpu_per_step_pair": (4 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
+           "grid_states_kept_GB_per_gpu": s.ops.ctx.get(1) / 1e9}
     return steps, warm, el, 1, roof, cfg, None, "strong"
 
 

@@ -110,28 +110,31 @@ int smo_transform(smo_ctx* ctx, int which, const double* in, double* out);
 
 /* ---- slab-decomposed 3-D case: one process per GPU -------------------------------------
  * With smo_config.world > 1 a KDYN context owns the kx-slab [rank*a/world, (rank+1)*a/world) of every coefficient
- * field and the y-slab of every grid field (vectors are then the LOCAL slabs [3][G][G/world][G]); smo_forward /
+ * field and the z-slab of every grid field (vectors are then the LOCAL slabs [3][G][G][G/world]); smo_forward /
  * smo_adjoint are replaced by phases between which the host layer performs the pencil transpose (an all-to-all of
- * `elems` complex128 per field group over RCCL: spheremanopt_amd/kdyn_slab.py).  The two exchange buffers hold
- * [peer][field group][3][a/world][G/world][G] complex128; peer blocks are contiguous, i.e. all_to_all_single-ready.
- *   y-side buffer: written by the y pass (before the exchange), read by it (after the exchange back)
- *   x-side buffer: read and overwritten in place by the fused x pass
+ * `elems` complex128 per field group over RCCL: spheremanopt_amd/kdyn_slab.py).  The transpose sits between the z
+ * and the y pass, where a field is smallest (16*a*m*G bytes per component).  The two exchange buffers hold
+ * [peer][field group][3][a/world][m][G/world] complex128; peer blocks are contiguous, i.e. all_to_all_single-ready.
+ *   z-side buffer: my kx, peer = z block; written by the inverse z pass, read by the forward z pass
+ *   y-side buffer: peer = kx block, my z; read by the inverse y pass, written by the forward y pass
  * Phases only enqueue work on the context's stream (see smo_set_stream); SMO_KD_ENERGY / SMO_KD_SYNC synchronise. */
 enum {
-    SMO_KD_SET_BUFFERS = 0,   /* p0 = y-side, p1 = x-side exchange buffer, each 2*elems complex128 (elems: SMO_KD_EXCHANGE_ELEMS) */
-    SMO_KD_EXCHANGE_ELEMS = 1,/* out <- complex128 elements of ONE field group summed over all peers (= 3*a*G*G/world^2 * world) */
-    SMO_KD_G2C_A = 2,         /* p0 = local grid vector: x pass grid -> spectrum into the x-side buffer   [then exchange x->y] */
-    SMO_KD_G2C_C = 3,         /* y,z passes + truncation; i0 = 0: store as snapshot 0 (B0), 1: store as scratch (U^)          */
-    SMO_KD_C2G_A = 4,         /* i0 = 0: dt*alpha*G^ (discrete grad B), 1: G^/scratch, 2: nu^ ; z,y passes  [then exchange y->x] */
-    SMO_KD_C2G_B = 5,         /* x pass spectrum -> grid; p0 = output local grid vector, NULL = the context's U field           */
-    SMO_KD_FWD_A = 6,         /* i0 = step n: z,y inverse passes of snapshot n                              [exchange y->x, 1 group] */
-    SMO_KD_FWD_B = 7,         /* i0 = n: fused x pass (c2r, U x B, r2c)                                     [exchange x->y, 1 group] */
-    SMO_KD_FWD_C = 8,         /* i0 = n: y,z forward passes + CNAB1 update -> snapshot n+1                                         */
-    SMO_KD_ENERGY = 9,        /* i0 = n: out <- this slab's share of <B_n,B_n> (synchronises)                                      */
-    SMO_KD_ADJ_INIT = 10,     /* i0 = adjoint_type: terminal condition from snapshot N                                             */
-    SMO_KD_ADJ_A = 11,        /* i0 = snapshot index: curl(G^) and B_f through z,y inverse passes          [exchange y->x, 2 groups] */
-    SMO_KD_ADJ_B = 12,        /* i0 = snapshot index: fused x pass (6 c2r, two cross products, 6 r2c)      [exchange x->y, 2 groups] */
-    SMO_KD_ADJ_C = 13,        /* i0 = snapshot index: y,z forward passes + G^, nu^ updates                                         */
+    SMO_KD_SET_BUFFERS = 0,   /* p0 = z-side, p1 = y-side exchange buffer, each 2*elems complex128 (elems: SMO_KD_EXCHANGE_ELEMS);
+                                 layout [peer][field group][3][a/W][m][G/W]: z side = my kx, peer's z block; y side = peer's kx, my z  */
+    SMO_KD_EXCHANGE_ELEMS = 1,/* out <- complex128 elements of ONE field group summed over all peers (= 3*(a/W)*m*G)                */
+    SMO_KD_G2C_A = 2,         /* p0 = local grid vector [3][G][G][G/W]: x, y passes grid -> spectrum           [then exchange y->z] */
+    SMO_KD_G2C_C = 3,         /* z pass + truncation; i0 = 0: store as snapshot 0 (B0), 1: store as scratch (U^)                     */
+    SMO_KD_C2G_A = 4,         /* i0 = 0: dt*alpha*G^ (discrete grad B), 1: G^/scratch, 2: nu^ ; z pass         [then exchange z->y] */
+    SMO_KD_C2G_B = 5,         /* y, x passes spectrum -> grid; p0 = output local grid vector, NULL = the context's U field           */
+    SMO_KD_FWD_A = 6,         /* i0 = step n: z inverse pass of snapshot n                                  [exchange z->y, 1 group] */
+    SMO_KD_FWD_B = 7,         /* i0 = n: y pass, fused x pass (c2r, U x B, r2c), y pass                     [exchange y->z, 1 group] */
+    SMO_KD_FWD_C = 8,         /* i0 = n: z forward pass + curl, projection, CNAB1 update -> snapshot n+1                             */
+    SMO_KD_ENERGY = 9,        /* i0 = n: out <- this slab's share of <B_n,B_n> (synchronises)                                        */
+    SMO_KD_ADJ_INIT = 10,     /* i0 = adjoint_type: terminal condition from snapshot N                                               */
+    SMO_KD_ADJ_A = 11,        /* i0 = snapshot index: z inverse pass of curl(G^) [and of B^_i0]       [exchange z->y, 1 or 2 groups:
+                                 1 when smo_get(ctx, 1) > 0 (grid-side states kept by the forward solve) and i0 < n_iters, else 2]   */
+    SMO_KD_ADJ_B = 12,        /* i0 = snapshot index: y passes, fused x pass (two cross products), y passes [exchange y->z, 2 groups] */
+    SMO_KD_ADJ_C = 13,        /* i0 = snapshot index: z forward passes + G^, nu^ updates                                             */
     SMO_KD_SYNC = 14          /* wait for the context's stream                                                                     */
 };
 int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double* out);

@@ -7,9 +7,12 @@
 //
 // Data layout in HBM (N = npts, a = N/2 kx modes, m = N-1 ky/kz modes, G = 3N/2 grid points per axis):
 //   coefficient fields  C [3][a][m][m]   complex128, kz fastest      (snapshot stack: [n][3][a][m][m])
-//   after the z pass    Tz[3][a][m][G]   complex128, z fastest
-//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slab-decomposed: [peer][field][3][a_loc][Gy_loc][G])
-//   grid fields         U [3][G][G][G]   float64,    z fastest       (= the reference's flat X vectors)
+//   after the z pass    Tz[3][a][m][G]   complex128, z fastest       (slab exchange layout: [peer][field group][3][a/W][m][G/W])
+//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slabs: [3][a][G][G/W], all kx, local z planes)
+//   grid fields         U [3][G][G][G]   float64,    z fastest       (= the reference's flat X vectors; slabs: [3][G][G][G/W])
+// Slab decomposition (W ranks): coefficient space is split over kx, grid space over z.  The z passes run on the kx slab, the y
+// and x passes on the z slab, and the exchange sits between the z and the y pass, where the data is smallest (16*a*m*G bytes per
+// component instead of 16*a*G*G after the y pass).  With W = 1 the "exchange buffer" is simply Tz.
 // One 3-D transform = three 1-D passes (z contiguous, y strided, x strided).  Every pass reads HBM in its first
 // Stockham stage (zero padding folded into the load) and writes HBM in its last (truncation folded into the store).
 // Fusions per time step:
@@ -31,8 +34,8 @@ struct Geom {
     int m;        // ky / kz modes (N-1)
     int kmax;     // (N-1)/2
     int G;        // grid points per axis (3N/2)
-    int Gyl;      // local y planes in grid space (G / world)
-    size_t blk;   // slab-exchange layout: elements between the blocks of consecutive peers (= fields * 3 * al * Gyl * G)
+    int Gzl;      // local z planes in grid space (G / world)
+    size_t blk;   // slab-exchange layout: elements between the blocks of consecutive peers (= field groups * 3 * al * m * Gzl)
     int utile;    // x pass spectrum -> grid: 1 = write the tile-major layout of the internal U field (u_off), 0 = the flat X layout
     double Rm, dt;
 };
@@ -44,15 +47,20 @@ __device__ __forceinline__ int wrap_pos(int pos, const Geom& g) {      // positi
 }
 __device__ __forceinline__ double wavenumber(int idx, const Geom& g) { return (idx <= g.kmax) ? (double)idx : (double)(idx - g.m); }
 
-// (y index) -> offset of the (c, ixl, y) line of z values in the slab-exchange layout of Ty
-__device__ __forceinline__ size_t ty_line(int c, int ixl, int y, const Geom& g) {
-    const int blk = y / g.Gyl, yy = y - blk * g.Gyl;
-    return (size_t)blk * g.blk + ((size_t)c * g.al + ixl) * ((size_t)g.Gyl * g.G) + (size_t)yy * g.G;
+// Tz in the slab-exchange layout [peer][field group][3][al][m][Gzl] (the field-group offset is folded into the base pointer):
+// z side: the peer index is the z block of `pos`; rt = ixl * m + iy is the local (kx, ky) row
+__device__ __forceinline__ size_t zs_off(int c, int rt, int pos, const Geom& g) {
+    const int p = pos / g.Gzl;
+    return (size_t)p * g.blk + ((size_t)c * (g.al * g.m) + rt) * g.Gzl + (pos - p * g.Gzl);
 }
-// x pass: offset of mode kx (global) of component c, flat local (y,z) index i
+// y side: the peer index is the kx block; offset of the (c, kx, iy = 0) row, z local
+__device__ __forceinline__ size_t ys_row0(int c, int kx, const Geom& g) {
+    const int q = kx / g.al;
+    return (size_t)q * g.blk + ((size_t)c * g.al + (kx - q * g.al)) * ((size_t)g.m * g.Gzl);
+}
+// x pass: offset of mode kx (global) of component c, flat local (y,z) index i, in Ty[3][a][G*Gzl]
 __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
-    const int blk = kx / g.al, kl = kx - blk * g.al;
-    return (size_t)blk * g.blk + ((size_t)c * g.al + kl) * ((size_t)g.Gyl * g.G) + i;
+    return ((size_t)c * g.a + kx) * ((size_t)g.G * g.Gzl) + i;
 }
 
 // The velocity field U is only ever read by the fused x passes, one (y,z) tile per workgroup, all x.  It is therefore kept
@@ -60,7 +68,7 @@ __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g)
 // G segments of 32-64 bytes (which cost 2-4x over-fetch of 128-byte lines).  Pairs (i, i+1) with i even never straddle a block.
 constexpr int UT = 4;
 __device__ __forceinline__ size_t u_off(int c, int x, size_t i, const Geom& g) {
-    const size_t nt = ((size_t)g.Gyl * g.G) / UT;
+    const size_t nt = ((size_t)g.G * g.Gzl) / UT;
     return (((size_t)c * nt + i / UT) * g.G + x) * UT + (i % UT);
 }
 
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, 
     };
     auto stN = [&](int b, int pos, cplx v) {
         const int tt = b / 3, c = b - 3 * tt, rt = rt0 + tt;
-        if (rt < nrt) out[((size_t)c * nrt + rt) * g.G + pos] = v;
+        if (rt < nrt) out[zs_off(c, rt, pos, g)] = v;
     };
     fft_inplace<L, true, NB, NT, false, false, false>(buf, L, tw, tid, ld0, stN);
 }
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
         const int c = b % 3, ft = b / 3, f = ft / NBT, tt = ft - f * NBT, rt = rt0 + tt;
         if (rt >= nrt) return mk(0, 0);
         const cplx* src = (f == 0) ? inA : inB;
-        return src[((size_t)c * nrt + rt) * g.G + pos];
+        return src[zs_off(c, rt, pos, g)];
     };
     if (MODE == ZF_PLAIN) {
         auto stN = [&](int b, int pos, cplx v) {
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// y pass (strided): Tz[3][al][m][G] <-> Ty (slab-exchange layout); ZT consecutive z per workgroup
+// y pass (strided): Tz (slab-exchange layout, all kx, local z) <-> Ty[3][a][G][Gzl]; ZT consecutive z per workgroup
 // ---------------------------------------------------------------------------------------------------------
 template <int L, bool INV, int ZT, int NT>
 __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw_g, Geom g) {
@@ -215,28 +223,29 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     const int tid = threadIdx.x;
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
     __syncthreads();
-    const int ntile = (g.G + ZT - 1) / ZT;
-    const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * al + ixl
-    const int c = o / g.al, ixl = o - c * g.al;
-    const cplx* tz = in;
+    const int ntile = (g.Gzl + ZT - 1) / ZT;
+    const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * a + kx
+    const int c = o / g.a, kx = o - c * g.a;
+    const size_t zrow = ys_row0(c, kx, g) + z0;                               // + idx * Gzl + b
+    const size_t trow = (size_t)o * g.G * g.Gzl + z0;                          // + y * Gzl + b
     if (INV) {
         auto ld0 = [&](int b, int pos) -> cplx {
             const int idx = wrap_pos(pos, g);
-            if (idx < 0 || z0 + b >= g.G) return mk(0, 0);
-            return tz[((size_t)o * g.m + idx) * g.G + z0 + b];
+            if (idx < 0 || z0 + b >= g.Gzl) return mk(0, 0);
+            return in[zrow + (size_t)idx * g.Gzl + b];
         };
         auto stN = [&](int b, int pos, cplx v) {
-            if (z0 + b < g.G) out[ty_line(c, ixl, pos, g) + z0 + b] = v;
+            if (z0 + b < g.Gzl) out[trow + (size_t)pos * g.Gzl + b] = v;
         };
         fft_inplace<L, true, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
     } else {
         auto ld0 = [&](int b, int pos) -> cplx {
-            if (z0 + b >= g.G) return mk(0, 0);
-            return in[ty_line(c, ixl, pos, g) + z0 + b];
+            if (z0 + b >= g.Gzl) return mk(0, 0);
+            return in[trow + (size_t)pos * g.Gzl + b];
         };
         auto stN = [&](int b, int pos, cplx v) {
             const int idx = wrap_pos(pos, g);
-            if (idx >= 0 && z0 + b < g.G) out[((size_t)o * g.m + idx) * g.G + z0 + b] = v;
+            if (idx >= 0 && z0 + b < g.Gzl) out[zrow + (size_t)idx * g.Gzl + b] = v;
         };
         fft_inplace<L, false, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
     }
@@ -263,7 +272,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
     constexpr int LD = L + 1;
-    const size_t plane = (size_t)g.Gyl * g.G;       // local (y,z) points
+    const size_t plane = (size_t)g.G * g.Gzl;       // local (y,z) points
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
 
@@ -436,9 +445,11 @@ class KDyn : public Context {
 public:
     explicit KDyn(const smo_config& c) { cfg = c; }
     Geom g{};
-    size_t nmode = 0, n_tz = 0, n_xb = 0, n_grid = 0, fld = 0;       // fld = 3*al*Gyl*G: one field group inside a peer block
-    cplx *d_stack = nullptr, *d_tzA = nullptr, *d_tzB = nullptr, *d_G = nullptr, *d_nu = nullptr, *d_tw = nullptr;
-    cplx *xs = nullptr, *xr = nullptr;      // exchange buffers: y-pass side / x-pass side (identical when world == 1)
+    size_t nmode = 0, tzb = 0, n_ex = 0, n_grid = 0, fld = 0;
+    // tzb = 3*al*m*Gzl: one field group of Tz inside a peer block of the exchange layout;  n_ex = 2*W*tzb: a whole exchange buffer
+    // fld = 3*a*G*Gzl:  one field group of Ty (all kx, local z planes) = what the x pass reads
+    cplx *d_stack = nullptr, *d_ty = nullptr, *d_G = nullptr, *d_nu = nullptr, *d_tw = nullptr;
+    cplx *zs = nullptr, *ys = nullptr;      // Tz exchange buffers: z-pass side / y-pass side (one and the same when world == 1)
     double *d_U = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     size_t n_part_rows = 1;
@@ -460,7 +471,7 @@ public:
         for (int n = w * ck; n < last; ++n) { SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n)); }
         return SMO_OK;
     }
-    Geom geom(int nfields) const { Geom q = g; q.blk = (size_t)nfields * fld; return q; }
+    Geom geom(int nfields) const { Geom q = g; q.blk = (size_t)nfields * tzb; return q; }
 
     int init() override {
         const int N = cfg.npts, W = cfg.world;
@@ -473,14 +484,14 @@ public:
             set_error("KDYN: %d slabs do not divide a=%d kx modes and G=%d grid planes", W, N / 2, 3 * N / 2);
             return SMO_ERR_UNSUPPORTED;
         }
-        g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gyl = g.G / W;
+        g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gzl = g.G / W;
         g.Rm = cfg.param; g.dt = cfg.dt;
         nmode = (size_t)g.al * g.m * g.m;
-        n_tz = (size_t)3 * g.al * g.m * g.G;
-        fld = (size_t)3 * g.al * g.Gyl * g.G;
-        n_xb = 2 * fld * W;                              // two field groups (adjoint) x peers
-        n_grid = (size_t)3 * g.G * g.Gyl * g.G;          // local slab of a grid vector: [3][G][Gyl][G]
-        g.blk = fld;
+        tzb = (size_t)3 * g.al * g.m * g.Gzl;
+        n_ex = 2 * tzb * W;                              // two field groups (adjoint) x peers
+        fld = (size_t)3 * g.a * g.G * g.Gzl;
+        n_grid = (size_t)3 * g.G * g.G * g.Gzl;          // local slab of a grid vector: [3][G][G][Gzl]
+        g.blk = tzb;
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
@@ -490,7 +501,7 @@ public:
         if (ck == 0) {                                       // smallest interval that fits the free HBM (keep 8 GB + work buffers spare)
             size_t free_b = 0, total_b = 0;
             SMO_HIP(hipMemGetInfo(&free_b, &total_b));
-            const size_t work = (2 * n_tz + n_xb + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)8 << 30);
+            const size_t work = (2 * n_ex + 2 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)8 << 30);
             for (ck = 1; ck < cfg.n_iters && stack_elems(ck) * sizeof(cplx) + work > free_b; ++ck) {}
         }
         if (ck > cfg.n_iters) ck = cfg.n_iters;
@@ -498,20 +509,19 @@ public:
         SMO_TRY(pool.upload(&d_tw, twiddles(g.G), stream));
         SMO_TRY(pool.alloc(&d_stack, ((size_t)cfg.n_iters / ck + 1) * 3 * nmode));
         if (ck > 1) SMO_TRY(pool.alloc(&d_scratch, (size_t)(ck - 1) * 3 * nmode));
-        {   // Ty stack: only when every snapshot is kept, on one GPU, and 16 GB of HBM stay free afterwards (SMO_KD_TYSTACK=0 disables)
+        {   // Ty stack: only when every snapshot is kept and 16 GB of HBM stay free afterwards (SMO_KD_TYSTACK=0 disables)
             const char* env = getenv("SMO_KD_TYSTACK");
             size_t free_b = 0, total_b = 0;
             SMO_HIP(hipMemGetInfo(&free_b, &total_b));
             const size_t need = (size_t)cfg.n_iters * fld * sizeof(cplx);
-            const size_t rest = (2 * n_tz + n_xb + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)16 << 30);
-            if (W == 1 && ck == 1 && !(env && atoi(env) == 0) && need + rest < free_b) {
+            const size_t rest = (2 * n_ex + 2 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)16 << 30);
+            if (ck == 1 && !(env && atoi(env) == 0) && need + rest < free_b) {
                 SMO_TRY(pool.alloc(&d_tystack, (size_t)cfg.n_iters * fld));
                 stack_bytes += need;
             }
         }
-        SMO_TRY(pool.alloc(&d_tzA, n_tz));
-        SMO_TRY(pool.alloc(&d_tzB, n_tz));
-        if (W == 1) { SMO_TRY(pool.alloc(&xs, n_xb)); xr = xs; }      // slabs: the host layer supplies xs / xr (SMO_KD_SET_BUFFERS)
+        SMO_TRY(pool.alloc(&d_ty, 2 * fld));
+        if (W == 1) { SMO_TRY(pool.alloc(&zs, n_ex)); ys = zs; }      // slabs: the host layer supplies zs / ys (SMO_KD_SET_BUFFERS)
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
@@ -519,7 +529,7 @@ public:
         SMO_TRY(pool.alloc(&d_part, n_part_rows * NPART));
         h_part.resize(n_part_rows * NPART);
         // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component, per slab)
-        const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.al * (double)g.G * g.G, S3 = 8.0 * (double)g.G * g.Gyl * g.G;
+        const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.a * (double)g.G * g.Gzl, S3 = 8.0 * (double)g.G * g.G * g.Gzl;
         k_zi = timing.add_class("kd_z_inverse", 3 * (S0 + S1));
         k_zic = timing.add_class("kd_z_inverse<curl>", 3 * (S0 + S1));
         k_yi = timing.add_class("kd_y_pass<inv>", 3 * (S1 + S2));
@@ -561,10 +571,13 @@ public:
     };
 
     int need_buffers() {
-        if (!xs || !xr) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
+        if (!zs || !ys) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
         return SMO_OK;
     }
-    int z_inverse(int mode, const cplx* in, cplx* out) {
+    // coefficients -> field group `f` (of `nf`) of the z-side exchange buffer
+    int z_inverse(int mode, const cplx* in, int f, int nf) {
+        const Geom g = geom(nf);
+        cplx* out = zs + (size_t)f * tzb;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -576,26 +589,32 @@ public:
             return SMO_OK;
         });
     }
-    // y pass between Tz and field group `f` of the y-side exchange buffer (layout with `nf` field groups per peer block)
-    int y_pass(bool inv, cplx* tz, int f, int nf, cplx* ex_override = nullptr) {
+    // y pass between field group `f` (of `nf`) of the y-side exchange buffer and one field group of Ty at `ty`
+    int y_pass(bool inv, int f, int nf, cplx* ty) {
         const Geom q = geom(nf);
-        cplx* ex = ex_override ? ex_override : xs + (size_t)f * fld;
+        cplx* ex = ys + (size_t)f * tzb;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
-            const int nwg = 3 * g.al * ((g.G + S::YZT - 1) / S::YZT);
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
-            if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, S::YZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)tz, ex, d_tw, q);
-            else hipLaunchKernelGGL((kd_y_pass<L, false, S::YZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, tz, d_tw, q);
+            auto launch = [&](auto zt) {
+                constexpr int ZT = decltype(zt)::value;
+                const int nwg = 3 * g.a * ((g.Gzl + ZT - 1) / ZT);
+                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, ty, d_tw, q);
+                else hipLaunchKernelGGL((kd_y_pass<L, false, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ty, ex, d_tw, q);
+            };
+            // thin slabs: halve the z tile when that avoids a mostly empty last tile (e.g. 128^3 on 8 GPUs: 24 local planes)
+            if (g.Gzl % S::YZT != 0 && g.Gzl % (S::YZT / 2) == 0) launch(std::integral_constant<int, S::YZT / 2>());
+            else launch(std::integral_constant<int, S::YZT>());
             return SMO_OK;
         });
     }
     // inA / inB: read the spectra of field group A / B from elsewhere (e.g. the Ty stack) instead of the x-side buffer
     int x_pass(int mode, const double* grid_in, double* grid_out, const cplx* inA = nullptr, const cplx* inB = nullptr) {
-        const size_t plane = (size_t)g.Gyl * g.G;
-        Geom q = geom(mode == X_FUSED_ADJ ? 2 : 1);
+        const size_t plane = (size_t)g.G * g.Gzl;
+        Geom q = g;
         q.utile = (mode == X_TO_GRID && grid_out == d_U) ? 1 : 0;
-        const XSpec sp{inA ? inA : xr, inB ? inB : xr + fld, xr, xr + fld};
+        const XSpec sp{inA ? inA : d_ty, inB ? inB : d_ty + fld, d_ty, d_ty + fld};
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
@@ -611,7 +630,10 @@ public:
             return SMO_OK;
         });
     }
-    int z_forward(int mode, const cplx* inA, const cplx* inB, cplx* out0, cplx* out1, const cplx* state0, const cplx* snp) {
+    // z-side exchange buffer (field groups 0 [and 1]) -> coefficients / time-step update
+    int z_forward(int mode, cplx* out0, cplx* out1, const cplx* state0, const cplx* snp) {
+        const Geom g = geom(mode == ZF_ADJ_UPDATE ? 2 : 1);
+        const cplx *inA = zs, *inB = zs + tzb;
         const double scale = 1.0 / ((double)g.G * g.G * g.G);
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
         return with_L([&](auto l) {
@@ -631,40 +653,49 @@ public:
         });
     }
 
-    // ---- phases: everything between two slab exchanges (the exchange x-side <-> y-side is the host layer's job) -------
-    // Ty stack (single GPU, keep-all): the y-pass output of B^_n is written to its own HBM slot instead of the exchange buffer; the
-    // adjoint step then reads B_f from there and skips the z and y passes of the snapshot (2 of its 8 kernels).
+    // ---- phases: everything between two slab exchanges (the exchange z-side <-> y-side is the host layer's job) -------
+    // Ty stack (keep-all, enough HBM): the inverse y pass of B^_n writes to its own HBM slot instead of the work buffer; the adjoint
+    // step then reads B_f from there: no z / y pass of the snapshot (2 of its 8 kernels) and, with slabs, one field group less to
+    // exchange.
     cplx* d_tystack = nullptr;
     cplx* tyslot(int n) { return d_tystack + (size_t)n * fld; }
-    bool have_ty(int n) const { return d_tystack != nullptr && n < cfg.n_iters; }
-    int fwd_A(int n) { SMO_TRY(z_inverse(ZI_PLAIN, snap(n), d_tzA)); return y_pass(true, d_tzA, 0, 1, have_ty(n) ? tyslot(n) : nullptr); }
-    int fwd_B(int n = -1) { return x_pass(X_FUSED_FWD, d_U, nullptr, (n >= 0 && have_ty(n)) ? tyslot(n) : nullptr); }
-    int fwd_C(int n) { SMO_TRY(y_pass(false, d_tzA, 0, 1)); return z_forward(ZF_FWD_UPDATE, d_tzA, nullptr, snap(n + 1), nullptr, snap(n), nullptr); }
+    bool have_ty(int n) const { return d_tystack != nullptr && n >= 0 && n < cfg.n_iters; }
+    int fwd_A(int n) { return z_inverse(ZI_PLAIN, snap(n), 0, 1); }
+    int fwd_B(int n = -1) {
+        cplx* ty = have_ty(n) ? tyslot(n) : d_ty;
+        SMO_TRY(y_pass(true, 0, 1, ty));
+        SMO_TRY(x_pass(X_FUSED_FWD, d_U, nullptr, ty));
+        return y_pass(false, 0, 1, d_ty);
+    }
+    int fwd_C(int n) { return z_forward(ZF_FWD_UPDATE, snap(n + 1), nullptr, snap(n), nullptr); }
     int adj_init(int adjoint_type) {
         ScopedTimer t(timing, k_misc, stream);
         hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(cfg.n_iters), d_G, d_nu, g, cfg.cost == SMO_COST_INTEGRATED ? 1 : 0,
                            adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
         return SMO_OK;
     }
+    // inverse side of an adjoint step carries omega only (1 field group) when B_f was kept by the forward solve, else omega and B^_idx
+    int adj_groups(int idx) const { return have_ty(idx) ? 1 : 2; }
     int adj_A(int idx) {
-        SMO_TRY(z_inverse(ZI_CURL, d_G, d_tzA));
-        SMO_TRY(y_pass(true, d_tzA, 0, 2));
-        if (have_ty(idx)) return SMO_OK;               // B_f on the y side was kept by the forward solve
-        SMO_TRY(z_inverse(ZI_PLAIN, snap(idx), d_tzB));
-        return y_pass(true, d_tzB, 1, 2);
+        const int nf = adj_groups(idx);
+        SMO_TRY(z_inverse(ZI_CURL, d_G, 0, nf));
+        return nf == 2 ? z_inverse(ZI_PLAIN, snap(idx), 1, 2) : SMO_OK;
     }
-    int adj_B(int idx = -1) { return x_pass(X_FUSED_ADJ, d_U, nullptr, nullptr, (idx >= 0 && have_ty(idx)) ? tyslot(idx) : nullptr); }
-    int adj_C(int idx) {
-        SMO_TRY(y_pass(false, d_tzA, 0, 2));
-        SMO_TRY(y_pass(false, d_tzB, 1, 2));
-        return z_forward(ZF_ADJ_UPDATE, d_tzA, d_tzB, d_G, d_nu, d_G, snap(idx));
+    int adj_B(int idx) {
+        const int nf = adj_groups(idx);
+        SMO_TRY(y_pass(true, 0, nf, d_ty));
+        if (nf == 2) SMO_TRY(y_pass(true, 1, 2, d_ty + fld));
+        SMO_TRY(x_pass(X_FUSED_ADJ, d_U, nullptr, nullptr, nf == 1 ? tyslot(idx) : nullptr));
+        SMO_TRY(y_pass(false, 0, 2, d_ty));
+        return y_pass(false, 1, 2, d_ty + fld);
     }
+    int adj_C(int idx) { return z_forward(ZF_ADJ_UPDATE, d_G, d_nu, d_G, snap(idx)); }
     // grid vector (local slab of the flat X layout) -> truncated coefficients, in two phases around the exchange
-    int g2c_A(const double* X) { return x_pass(X_FROM_GRID, X, nullptr); }
-    int g2c_C(cplx* out) { SMO_TRY(y_pass(false, d_tzA, 0, 1)); return z_forward(ZF_PLAIN, d_tzA, nullptr, out, nullptr, nullptr, nullptr); }
+    int g2c_A(const double* X) { SMO_TRY(x_pass(X_FROM_GRID, X, nullptr)); return y_pass(false, 0, 1, d_ty); }
+    int g2c_C(cplx* out) { return z_forward(ZF_PLAIN, out, nullptr, nullptr, nullptr); }
     // coefficients -> grid; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
-    int c2g_A(const cplx* C, bool scaled) { SMO_TRY(z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, d_tzA)); return y_pass(true, d_tzA, 0, 1); }
-    int c2g_B(double* X) { return x_pass(X_TO_GRID, nullptr, X); }
+    int c2g_A(const cplx* C, bool scaled) { return z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, 0, 1); }
+    int c2g_B(double* X) { SMO_TRY(y_pass(true, 0, 1, d_ty)); return x_pass(X_TO_GRID, nullptr, X); }
 
     int reduce_partials(double* out) {
         SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -769,10 +800,10 @@ public:
         (void)i1;
         if (op == SMO_KD_SET_BUFFERS) {
             if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
-            xs = static_cast<cplx*>(p0); xr = static_cast<cplx*>(p1);
+            zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1);
             return SMO_OK;
         }
-        if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(fld * cfg.world); return SMO_OK; }
+        if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(tzb * cfg.world); return SMO_OK; }
         SMO_TRY(need_buffers());
         const int N = cfg.n_iters;
         auto step_ok = [&](int n, int hi) { if (n < 0 || n > hi) { set_error("smo_kdyn_op(%d): index %d out of range", op, n); return false; } return true; };
@@ -790,7 +821,7 @@ public:
                 if (!have_forward) { set_error("smo_kdyn_op: adjoint before forward"); return SMO_ERR_STATE; }
                 rc = adj_init(i0); break;
             case SMO_KD_ADJ_A: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_A(i0); break;
-            case SMO_KD_ADJ_B: rc = adj_B(i0); break;
+            case SMO_KD_ADJ_B: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_B(i0); break;
             case SMO_KD_ADJ_C: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_C(i0); break;
             case SMO_KD_SYNC: SMO_HIP(hipStreamSynchronize(stream)); break;
             default: set_error("smo_kdyn_op: unknown op %d", op); return SMO_ERR_ARG;

@@ -1,17 +1,20 @@
 """Slab-decomposed kinematic dynamo over the GPUs of one node: one process per GPU, RCCL all-to-all pencil transposes.
 
 Parallel layout (the reference gets the same decomposition implicitly from Dedalus' MPI layouts):
-  * coefficient space is split over kx   (rank r owns kx in [r*a/W, (r+1)*a/W))  -> z and y passes are local
-  * grid space is split over y           (rank r owns y  in [r*G/W, (r+1)*G/W))  -> the x pass and all grid products are local
-  * between them ONE all-to-all per direction per step, carrying all 3 (forward) / 6 (adjoint) fields at once;
-    the device kernels write/read the exchange buffers as [peer][field group][3][a/W][G/W][G], i.e. contiguous per peer.
+  * coefficient space is split over kx   (rank r owns kx in [r*a/W, (r+1)*a/W))  -> the z pass and the per-mode solves are local
+  * grid space is split over z           (rank r owns z  in [r*G/W, (r+1)*G/W))  -> the y and x passes and all grid products are local
+  * between the z and the y pass ONE all-to-all per direction per step, carrying all fields of that direction at once, at the point
+    where the data is smallest (16*a*m*G bytes per component; after the y pass it would be 16*a*G*G, 1.5x more); the device
+    kernels write/read the exchange buffers as [peer][field group][3][a/W][m][G/W], i.e. contiguous per peer.
+  * when the HBM allows it the forward solve keeps B_n on the y side (after exchange and y pass) for every step, so an adjoint step
+    exchanges omega only on its inverse side: 5 field-group exchanges per forward+adjoint step pair instead of 6.
   * scalars (J, <x,y>) are all-reduced; the snapshot stack (1/W of it per GPU), the per-mode solves and the
     products need no communication.
 
 The time loop only *enqueues* work: the device phases (``smo_kdyn_op``) and the collectives run on the same HIP stream
 (torch's current stream), so there is no host synchronisation inside a solve with the NCCL(=RCCL) backend.
 
-`SlabKDyn.forward / adjoint / inner` work on LOCAL slabs ([3][G][G/W][G] float64 tensors on the device).
+`SlabKDyn.forward / adjoint / inner` work on LOCAL slabs ([3][G][G][G/W] float64 tensors on the device).
 The module-level callables keep the reference's replicated-vector semantics (FWD_Solve_KDyn.py:91-171: every rank holds the
 full vectors; gradients are all-gathered), so ``Optimise_On_Multi_Sphere`` runs unchanged, redundantly on every rank.
 """
@@ -60,8 +63,13 @@ class HipOps:
         ref = C.byref(out) if out is not None else None
         _capi._check(self.lib.smo_kdyn_op(self.ctx._h, code, int(i0), 0, C.c_void_p(p0), C.c_void_p(p1), ref))
 
-    def set_buffers(self, ys, xs):
-        self.op(SET_BUFFERS, p0=ys.data_ptr(), p1=xs.data_ptr())
+    def set_buffers(self, zs, ys):
+        self.op(SET_BUFFERS, p0=zs.data_ptr(), p1=ys.data_ptr())
+
+    @property
+    def keeps_grid_states(self):
+        """True when the forward solve keeps B_n on the y side (the adjoint's inverse exchange then carries one field group)."""
+        return self.ctx.get(1) > 0
 
     def energy(self, n):
         out = self._C.c_double()
@@ -92,7 +100,7 @@ class SlabKDyn:
         self.Rm, self.dt, self.n_iters, self.cost = float(Rm), float(dt), int(N_ITERS), Cost_function
         if (self.N // 2) % self.world or self.G % self.world:
             raise ValueError("%d slabs do not divide a=%d / G=%d" % (self.world, self.N // 2, self.G))
-        self.Gyl = self.G // self.world
+        self.Gzl = self.G // self.world
         self.stream = None
         if ops is None:
             if device is None:
@@ -106,9 +114,10 @@ class SlabKDyn:
         self.ops = ops
         self.elems = ops.elems                                  # complex128 per field group, all peers
         # exchange buffers as float64 pairs (RCCL has no complex type): 2 field groups x elems complex128
-        self.buf_y = torch.zeros(4 * self.elems, dtype=torch.float64, device=self.dev)
-        self.buf_x = self.buf_y if self.world == 1 else torch.zeros_like(self.buf_y)
-        ops.set_buffers(self.buf_y, self.buf_x)
+        self.buf_z = torch.zeros(4 * self.elems, dtype=torch.float64, device=self.dev)      # z-pass side (kx slab, all z)
+        self.buf_y = self.buf_z if self.world == 1 else torch.zeros_like(self.buf_z)        # y-pass side (all kx, z slab)
+        ops.set_buffers(self.buf_z, self.buf_y)
+        self.adj_groups = 1 if ops.keeps_grid_states else 2
         backend = _dist().get_backend() if self.world > 1 else None
         # collectives on device tensors need RCCL; with gloo (CPU tests, or several ranks sharing one GPU) stage through the host
         self.host_staged = (self.dev.type == "cuda" and backend == "gloo") if stage_through_host is None else stage_through_host
@@ -140,12 +149,12 @@ class SlabKDyn:
     # -- transforms of whole vectors ------------------------------------------------------------------------------------
     def _grid_to_coeff(self, vec, target):
         self.ops.phase(G2C_A, vec=vec)
-        self._exchange(self.buf_x, self.buf_y, 1)
+        self._exchange(self.buf_y, self.buf_z, 1)
         self.ops.phase(G2C_C, target)
 
     def _coeff_to_grid(self, source, vec):
         self.ops.phase(C2G_A, source)
-        self._exchange(self.buf_y, self.buf_x, 1)
+        self._exchange(self.buf_z, self.buf_y, 1)
         self.ops.phase(C2G_B, vec=vec)
 
     # -- the three callbacks on local slabs --------------------------------------------------------------------------------
@@ -186,11 +195,11 @@ class SlabKDyn:
         for n in range(self.n_iters):
             if integ:
                 J += self.dt * self.ops.energy(n)
-            self.ops.phase(FWD_A, n)
-            self._exchange(self.buf_y, self.buf_x, 1)
-            self.ops.phase(FWD_B, n)
-            self._exchange(self.buf_x, self.buf_y, 1)
-            self.ops.phase(FWD_C, n)
+            self.ops.phase(FWD_A, n)                       # z pass (inverse)
+            self._exchange(self.buf_z, self.buf_y, 1)
+            self.ops.phase(FWD_B, n)                       # y, x passes, U x B on the grid, x, y passes back
+            self._exchange(self.buf_y, self.buf_z, 1)
+            self.ops.phase(FWD_C, n)                       # z pass (forward) + curl, projection, CNAB1 update
         E = self.ops.energy(self.n_iters)
         J = J + self.dt * E if integ else E
         self.have_forward = True
@@ -204,9 +213,9 @@ class SlabKDyn:
         idx = self.n_iters if cont else self.n_iters - 1
         for _ in range(self.n_iters):
             self.ops.phase(ADJ_A, idx)
-            self._exchange(self.buf_y, self.buf_x, 2)
+            self._exchange(self.buf_z, self.buf_y, self.adj_groups if idx < self.n_iters else 2)
             self.ops.phase(ADJ_B, idx)
-            self._exchange(self.buf_x, self.buf_y, 2)
+            self._exchange(self.buf_y, self.buf_z, 2)
             self.ops.phase(ADJ_C, idx)
             idx -= 1
         if out is None:
@@ -224,15 +233,15 @@ class SlabKDyn:
 
     # -- replicated-vector helpers (the reference's Vec_to_Field / Field_to_Vec across ranks) ------------------------------------
     def local_slab(self, full):
-        """Full flat vector [3][G][G][G] (NumPy or tensor, any device) -> this rank's y-slab as a flat device tensor."""
-        G, y0 = self.G, self.rank * self.Gyl
+        """Full flat vector [3][G][G][G] (NumPy or tensor, any device) -> this rank's z-slab as a flat device tensor."""
+        G, z0 = self.G, self.rank * self.Gzl
         t = self.torch.as_tensor(np.asarray(full, dtype=np.float64) if not self.torch.is_tensor(full) else full)
-        return t.reshape(3, G, G, G)[:, :, y0:y0 + self.Gyl, :].contiguous().reshape(-1).to(self.dev)
+        return t.reshape(3, G, G, G)[:, :, :, z0:z0 + self.Gzl].contiguous().reshape(-1).to(self.dev)
 
     def gather_full(self, local):
-        """Local slab -> full flat NumPy vector on every rank (all-gather over y)."""
+        """Local slab -> full flat NumPy vector on every rank (all-gather over z)."""
         G = self.G
-        loc = local.reshape(3, G, self.Gyl, G)
+        loc = local.reshape(3, G, G, self.Gzl)
         if self.world == 1:
             return loc.reshape(-1).cpu().numpy()
         dist = _dist()
@@ -240,7 +249,7 @@ class SlabKDyn:
         src = loc.cpu().contiguous() if staged else loc.contiguous()
         parts = [self.torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src)
-        return self.torch.cat(parts, dim=2).reshape(-1).cpu().numpy()
+        return self.torch.cat(parts, dim=3).reshape(-1).cpu().numpy()
 
 
 # ---- the reference's callback surface on top of the slab solver (replicated full vectors in / out) -----------------------------

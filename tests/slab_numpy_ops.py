@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: a NumPy phase backend for spheremanopt_amd.kdyn_slab.SlabKDyn, used to cover the N>1 driver logic
 (exchange layout, phase order, reductions) with world_size-2 gloo runs on the CPU.  It restates, per slab, what the HIP
-phases of csrc/kdyn.hip do, reading/writing the exchange buffers in exactly their [peer][field][3][a/W][G/W][G] layout,
+phases of csrc/kdyn.hip do, reading/writing the exchange buffers in exactly their [peer][field][3][a/W][m][G/W] layout,
 and borrows the per-mode algebra from the oracle."""
 import numpy as np
 from scipy import fft as sfft
@@ -12,76 +12,72 @@ from spheremanopt_amd.kdyn_slab import (ADJ_A, ADJ_B, ADJ_C, ADJ_INIT, C2G_A, C2
 class NumpyOps:
     device = "cpu"
 
-    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function, rank, world):
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function, rank, world, keeps_grid_states=True):
         o = KDynOracle(Npts, Rm=Rm, dt=dt, N_ITERS=N_ITERS, Cost_function=Cost_function)
         self.o, self.rank, self.W = o, rank, world
         self.G, self.a, self.m = o.G, o.a, o.m
-        self.al, self.Gyl = o.a // world, o.G // world
+        self.al, self.Gzl = o.a // world, o.G // world
         self.ix0 = rank * self.al
         sl = slice(self.ix0, self.ix0 + self.al)
         for name in ("K", "k2", "k2s", "zero", "alpha", "beta"):          # restrict the per-mode tables to this kx slab
             arr = getattr(o, name)
             setattr(o, name, arr[:, sl] if name == "K" else arr[sl])
-        self.elems = 3 * self.al * self.Gyl * self.G * world
-        self.vec_len = 3 * self.G * self.Gyl * self.G
+        self.elems = 3 * self.al * self.m * self.Gzl * world
+        self.vec_len = 3 * self.G * self.G * self.Gzl
         self.n_iters, self.dt, self.cost = N_ITERS, dt, Cost_function
         self.stack = np.zeros((N_ITERS + 1, 3, self.al, self.m, self.m), dtype=complex)
+        self.keeps_grid_states = keeps_grid_states                        # the device's "Ty stack": B_n on the grid side, per step
+        self.Bgrid = {}
         self.Gh = self.nu = self.scratch = None
         self.U = None
 
-    # -- buffers ---------------------------------------------------------------------------------------------------------
-    def set_buffers(self, ys, xs):
-        self.by, self.bx = ys.numpy().view(np.complex128), xs.numpy().view(np.complex128)
+    # -- buffers: [peer][field group][3][al][m][Gzl] on both sides -----------------------------------------------------------
+    def set_buffers(self, zs, ys):
+        self.bz, self.by = zs.numpy().view(np.complex128), ys.numpy().view(np.complex128)
 
-    def _yview(self, nf):
-        return self.by[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.Gyl, self.G)
+    def _view(self, buf, nf):
+        return buf[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.m, self.Gzl)
 
-    def _xview(self, nf):
-        return self.bx[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.Gyl, self.G)
+    def _put_z(self, Tz, f, nf):          # Tz: (3, al, m, G): my kx, all z -> peer = z block
+        self._view(self.bz, nf)[:, f] = Tz.reshape(3, self.al, self.m, self.W, self.Gzl).transpose(3, 0, 1, 2, 4)
 
-    def _put_y(self, Ty, f, nf):          # Ty: (3, al, G, G) -> blocks over y
-        v = Ty.reshape(3, self.al, self.W, self.Gyl, self.G).transpose(2, 0, 1, 3, 4)
-        self._yview(nf)[:, f] = v
+    def _get_z(self, f, nf):
+        return self._view(self.bz, nf)[:, f].transpose(1, 2, 3, 0, 4).reshape(3, self.al, self.m, self.G)
 
-    def _get_y(self, f, nf):
-        return self._yview(nf)[:, f].transpose(1, 2, 0, 3, 4).reshape(3, self.al, self.G, self.G)
+    def _get_y(self, f, nf):              # -> (3, a, m, Gzl): all kx (peer = kx block), my z
+        return self._view(self.by, nf)[:, f].transpose(1, 0, 2, 3, 4).reshape(3, self.a, self.m, self.Gzl)
 
-    def _get_x(self, f, nf):              # -> (3, a, Gyl, G): all kx, local y
-        return self._xview(nf)[:, f].transpose(1, 0, 2, 3, 4).reshape(3, self.a, self.Gyl, self.G)
-
-    def _put_x(self, Tx, f, nf):
-        self._xview(nf)[:, f] = Tx.reshape(3, self.W, self.al, self.Gyl, self.G).transpose(1, 0, 2, 3, 4)
+    def _put_y(self, T, f, nf):
+        self._view(self.by, nf)[:, f] = T.reshape(3, self.W, self.al, self.m, self.Gzl).transpose(1, 0, 2, 3, 4)
 
     # -- 1-D passes on slabs -----------------------------------------------------------------------------------------------
-    def _zy_inverse(self, C):
+    def _z_inverse(self, C):              # (3, al, m, m) -> (3, al, m, G)
         o, G = self.o, self.G
         p = np.zeros((3, self.al, self.m, G), dtype=complex); p[..., o.sel] = C
-        p = sfft.ifft(p, axis=3) * G
-        q = np.zeros((3, self.al, G, G), dtype=complex); q[:, :, o.sel] = p
-        return sfft.ifft(q, axis=2) * G
+        return sfft.ifft(p, axis=3) * G
 
-    def _yz_forward(self, Ty):
-        o = self.o
-        c = sfft.fft(Ty, axis=2)[:, :, o.sel]
-        c = sfft.fft(c, axis=3)[..., o.sel]
-        return c / float(self.G) ** 3
+    def _z_forward(self, Tz):
+        return sfft.fft(Tz, axis=3)[..., self.o.sel] / float(self.G) ** 3
 
-    def _x_to_grid(self, Tx):
-        G = self.G
-        r = np.zeros((3, G // 2 + 1, self.Gyl, G), dtype=complex); r[:, :self.a] = Tx
+    def _yx_to_grid(self, T):             # (3, a, m, Gzl) -> real (3, G, G, Gzl)
+        o, G = self.o, self.G
+        q = np.zeros((3, self.a, G, self.Gzl), dtype=complex); q[:, :, o.sel] = T
+        q = sfft.ifft(q, axis=2) * G
+        r = np.zeros((3, G // 2 + 1, G, self.Gzl), dtype=complex); r[:, :self.a] = q
         return sfft.irfft(r, n=G, axis=1) * G
 
-    def _x_from_grid(self, g):
-        return sfft.rfft(g, axis=1)[:, :self.a]
+    def _xy_from_grid(self, g):
+        c = sfft.rfft(g, axis=1)[:, :self.a]
+        return sfft.fft(c, axis=2)[:, :, self.o.sel]
 
     # -- phases ------------------------------------------------------------------------------------------------------------
     def phase(self, code, i0=0, vec=None):
         o = self.o
-        grid = (lambda t: t.numpy().reshape(3, self.G, self.Gyl, self.G)) if vec is not None else None
+        grid = (lambda t: t.numpy().reshape(3, self.G, self.G, self.Gzl)) if vec is not None else None
         if code == G2C_A:
-            self._put_x(self._x_from_grid(grid(vec)), 0, 1)
+            self._put_y(self._xy_from_grid(grid(vec)), 0, 1)
         elif code == G2C_C:
-            c = self._yz_forward(self._get_y(0, 1))
+            c = self._z_forward(self._get_z(0, 1))
             if i0 == 0:
                 self.stack[0] = c
             else:
@@ -90,20 +86,22 @@ class NumpyOps:
             # source 1 is "the G^/scratch array": scratch (U^) during the forward set-up, G^ once the adjoint has started
             src = {0: lambda: self.dt * o.alpha * self.Gh, 1: lambda: self.scratch if self.Gh is None else self.Gh,
                    2: lambda: self.nu}[i0]()
-            self._put_y(self._zy_inverse(src), 0, 1)
+            self._put_z(self._z_inverse(src), 0, 1)
         elif code == C2G_B:
-            g = self._x_to_grid(self._get_x(0, 1))
+            g = self._yx_to_grid(self._get_y(0, 1))
             if vec is None:
                 self.U = g
             else:
                 grid(vec)[...] = g
         elif code == FWD_A:
-            self._put_y(self._zy_inverse(self.stack[i0]), 0, 1)
+            self._put_z(self._z_inverse(self.stack[i0]), 0, 1)
         elif code == FWD_B:
-            Bg = self._x_to_grid(self._get_x(0, 1))
-            self._put_x(self._x_from_grid(o.cross(self.U, Bg)), 0, 1)
+            Bg = self._yx_to_grid(self._get_y(0, 1))
+            if self.keeps_grid_states:
+                self.Bgrid[i0] = Bg
+            self._put_y(self._xy_from_grid(o.cross(self.U, Bg)), 0, 1)
         elif code == FWD_C:
-            E = self._yz_forward(self._get_y(0, 1))
+            E = self._z_forward(self._get_z(0, 1))
             self.stack[i0 + 1] = o.cnab_update(self.stack[i0], o.curl(E))
         elif code == ADJ_INIT:
             BN = self.stack[self.n_iters]
@@ -114,15 +112,20 @@ class NumpyOps:
                 self.Gh = o.project(-2. * BN) / scale
                 self.Gh[:, o.zero] = 0.
             self.nu = np.zeros_like(self.Gh)
-        elif code == ADJ_A:
-            self._put_y(self._zy_inverse(o.curl(self.Gh)), 0, 2)
-            self._put_y(self._zy_inverse(self.stack[i0]), 1, 2)
-        elif code == ADJ_B:
-            om = self._x_to_grid(self._get_x(0, 2)); Bf = self._x_to_grid(self._get_x(1, 2))
-            self._put_x(self._x_from_grid(o.cross(om, self.U)), 0, 2)
-            self._put_x(self._x_from_grid(o.cross(om, Bf)), 1, 2)
+        elif code in (ADJ_A, ADJ_B):
+            kept = self.keeps_grid_states and i0 < self.n_iters      # B_f is on the grid side already: omega travels alone
+            nf = 1 if kept else 2
+            if code == ADJ_A:
+                self._put_z(self._z_inverse(o.curl(self.Gh)), 0, nf)
+                if not kept:
+                    self._put_z(self._z_inverse(self.stack[i0]), 1, 2)
+            else:
+                om = self._yx_to_grid(self._get_y(0, nf))
+                Bf = self.Bgrid[i0] if kept else self._yx_to_grid(self._get_y(1, 2))
+                self._put_y(self._xy_from_grid(o.cross(om, self.U)), 0, 2)
+                self._put_y(self._xy_from_grid(o.cross(om, Bf)), 1, 2)
         elif code == ADJ_C:
-            F1 = self._yz_forward(self._get_y(0, 2)); F2 = -self._yz_forward(self._get_y(1, 2))
+            F1 = self._z_forward(self._get_z(0, 2)); F2 = -self._z_forward(self._get_z(1, 2))
             if self.cost == "Integrated":
                 F1 = F1 - 2. * self.stack[i0]
             nu, K = self.nu, o.K

@@ -1,6 +1,7 @@
 """Slab-decomposed KDyn on real hardware.  The box has ONE GPU, so: (a) world = 1 through the phase-level C-ABI
 (smo_kdyn_op) must equal the monolithic path; (b) two processes share cuda:0 and exchange through gloo (host-staged) —
-this exercises the slab geometry of the HIP kernels (a/W kx modes, G/W y planes, per-peer blocks) against the oracle."""
+this exercises the slab geometry of the HIP kernels (a/W kx modes, G/W z planes, per-peer blocks of the exchange between the z and
+the y pass) against the oracle, with and without the kept grid-side states (one or two field groups on the adjoint's way in)."""
 import os
 import socket
 import sys
@@ -43,8 +44,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, n, cost, adj, out):
+def _worker(rank, world, port, N, n, cost, adj, keep, out):
     sys.path.insert(0, ROOT)
+    os.environ["SMO_KD_TYSTACK"] = "1" if keep else "0"
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -66,14 +68,15 @@ def _worker(rank, world, port, N, n, cost, adj, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,world,cost,adj", [(16, 2, "Final", "Discrete"), (32, 4, "Integrated", "Discrete"),
-                                              (16, 2, "Final", "Continuous")])
-def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj):
+@pytest.mark.parametrize("N,world,cost,adj,keep", [(16, 2, "Final", "Discrete", True), (32, 4, "Integrated", "Discrete", False),
+                                                   (16, 2, "Final", "Continuous", True), (48, 4, "Final", "Discrete", True),
+                                                   (32, 2, "Final", "Discrete", False)])
+def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep):
     import torch.multiprocessing as mp
     from oracle.kdyn import KDynOracle
     n = 3
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, out), nprocs=world, join=True)
     r = np.load(out)
     o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
     Jo = o.forward([r["B"], r["U"]]); goB, goU = o.adjoint([r["B"], r["U"]], adj)
