@@ -156,27 +156,13 @@ def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
                       "path, %d thread(s)), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers, el)}
 
 
-def bench_kdyn_slab(a, torch, rank, world):
-    """N > 1: ONE 128^3 gradient slab-decomposed over the N GPUs (strong scaling), RCCL all-to-all pencil transposes."""
+def _slab_run(torch, N, Rm, dt, n_iters, steps, warm):
+    """Build the slab solver for an N^3 problem on this rank's GPU and time `steps` gradients (barrier + sync on both sides)."""
     from spheremanopt_amd import kdyn
     from spheremanopt_amd.kdyn_slab import SlabKDyn
-    N = a.npts or 128
-    Rm, dt = 1.0, 1e-3
-    n_iters = a.iters or 1000
-    steps = a.steps if a.steps is not None else 2
-    warm = a.warmup if a.warmup is not None else 1
     G = 3 * N // 2
-    Bfull, Ufull = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
-    # integrity check of the decomposition: rank 0 first evaluates J on its own GPU with the single-GPU path (same kernels, no
-    # exchange); every rank's slab result must agree with it to 1e-9 relative
-    J_single = torch.zeros(1, dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
-    if rank == 0:
-        dom1 = kdyn.KDynDomain(N, device=torch.cuda.current_device())
-        J_single[0] = dom1.context(Rm, dt, n_iters, "Final").forward([Bfull, Ufull])
-        dom1.drop_contexts()
-    torch.distributed.broadcast(J_single, 0)
     s = SlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device())
-    Bl = s.local_slab(Bfull); Ul = s.local_slab(Ufull)
+    Bl = s.local_slab(kdyn.synthetic_field(G, 1)); Ul = s.local_slab(kdyn.synthetic_field(G, 2))
     out = [torch.empty_like(Bl), torch.empty_like(Ul)]
     for _ in range(warm):
         s.forward([Bl, Ul]); s.adjoint("Discrete", out)
@@ -188,7 +174,27 @@ def bench_kdyn_slab(a, torch, rank, world):
         J = s.forward([Bl, Ul]); s.adjoint("Discrete", out)
     torch.cuda.synchronize()
     torch.distributed.barrier()
-    el = time.perf_counter() - t0
+    return s, J, time.perf_counter() - t0
+
+
+def bench_kdyn_slab(a, torch, rank, world):
+    """N > 1: ONE 128^3 gradient slab-decomposed over the N GPUs (strong scaling), RCCL all-to-all pencil transposes."""
+    from spheremanopt_amd import kdyn
+    N = a.npts or 128
+    Rm, dt = 1.0, 1e-3
+    n_iters = a.iters or 1000
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup is not None else 1
+    G = 3 * N // 2
+    # integrity check of the decomposition: rank 0 first evaluates J on its own GPU with the single-GPU path (same kernels, no
+    # exchange); every rank's slab result must agree with it to 1e-9 relative
+    J_single = torch.zeros(1, dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
+    if rank == 0:
+        dom1 = kdyn.KDynDomain(N, device=torch.cuda.current_device())
+        J_single[0] = dom1.context(Rm, dt, n_iters, "Final").forward([kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)])
+        dom1.drop_contexts()
+    torch.distributed.broadcast(J_single, 0)
+    s, J, el = _slab_run(torch, N, Rm, dt, n_iters, steps, warm)
     tim = s.ops.ctx.timing()
     tot_ms = sum(t["total_ms"] for t in tim)
     dom_k = max(tim, key=lambda t: t["total_ms"])
@@ -207,6 +213,26 @@ def bench_kdyn_slab(a, torch, rank, world):
                           "step pair)" % (world, 4 + s.adj_groups),
            "exchange_MB_sent_per_gpu_per_step_pair": (4 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
            "grid_states_kept_GB_per_gpu": s.ops.ctx.get(1) / 1e9}
+    # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)
+    big = int(os.environ.get("SMO_BENCH_SLAB_EXTRA_NPTS", "256"))
+    if a.npts is None and a.iters is None and not a.no_secondary and cfg["slab_J_matches_single_gpu"] and (big // 2) % world == 0:
+        del s
+        torch.cuda.empty_cache()
+        # every rank must be able to hold its 1/W of the snapshot stack plus work buffers; decide collectively, before any allocation
+        need = (n_iters + 1) * 3 * (big // 2 // world) * (big - 1) ** 2 * 16 + 40 * (3 * big // 2) ** 3 * 8 // world + (8 << 30)
+        ok = torch.tensor([1.0 if torch.cuda.mem_get_info()[0] > need else 0.0], dtype=torch.float64, device=J_single.device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        try:
+            if ok.item() < 0.5:
+                raise MemoryError("%d^3 needs %.0f GB per GPU at %d slabs" % (big, need / 1e9, world))
+            s2, J2, el2 = _slab_run(torch, big, Rm, dt, n_iters, 1, 0)
+            cfg["config_256"] = {"workload": "Kinematic dynamo 3D Fourier %d^3 slab-decomposed across %d GPUs, T=%g, dt=%g" % (big, world, dt * n_iters, dt),
+                                 "ms_per_gradient": 1e3 * el2, "gradient_evals_per_s": 1.0 / el2, "steps": 1, "warmup": 0, "J": J2,
+                                 "stack_GB_per_gpu": s2.ops.ctx.stack_bytes / 1e9,
+                                 "exchange_MB_sent_per_gpu_per_step_pair": (4 + s2.adj_groups) * s2.elems * 16 / 1e6 * (world - 1) / world}
+            del s2
+        except Exception as e:                       # never lose the main line because of the extra
+            cfg["config_256"] = {"error": repr(e)}
     return steps, warm, el, 1, roof, cfg, None, "strong"
 
 
