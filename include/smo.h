@@ -16,6 +16,9 @@
  *                    ADJ_Solve_IVP_Discrete FWD_Solve_SHB23.py:796-920
  *   smo_inner     <- Inner_Prod             FWD_Solve_SH23.py:158-172, Inner_Prod_3 FWD_Solve_KDyn.py:173-181,
  *                    Inner_Prod_Discrete    FWD_Solve_SHB23.py:189-193
+ *   SMO_POIS (stratified plane-Poiseuille optimal mixing, "Discrete" formulation): smo_forward <- FWD_Solve_Discrete
+ *                    FWD_Solve_Poiseuille.py:777-1155, smo_adjoint <- ADJ_Solve_Discrete :1320-1659, smo_inner <- Inner_Prod_Discrete
+ *                    :282-299, smo_transform <- transform / transformInverse / transformAdjoint / transformInverseAdjoint :44-89
  *
  * Conventions
  *   - every function returns SMO_OK (0) or an error code; smo_last_error() gives the message (thread local).
@@ -23,6 +26,7 @@
  *       SH23 : 1 component, G = 2*npts values on the scale-2 Fourier grid
  *       SHB23: 1 component, npts values on the ascending Gauss-Chebyshev grid
  *       KDYN : 2 components (B0, U), each 3*G^3 (x,y,z parts concatenated, each C-ordered [x][y][z]), G = 3*npts/2
+ *       POIS : 1 component [u.flatten(), w.flatten()] of the (Nx, Nz) grids, z fastest (Field_to_Vec, FWD_Solve_Poiseuille.py:160-207)
  *   - "_dev" entry points take pointers into the HBM of the context's device (no copies); the plain ones take
  *     caller-owned host buffers and stage them through context-owned device buffers.
  *   - all entry points are synchronous (return after the context's stream has drained).
@@ -47,13 +51,14 @@ typedef struct smo_ctx smo_ctx;
 enum { SMO_OK = 0, SMO_ERR_ARG = 1, SMO_ERR_NO_DEVICE = 2, SMO_ERR_HIP = 3, SMO_ERR_STATE = 4, SMO_ERR_NOMEM = 5,
        SMO_ERR_UNSUPPORTED = 6 };
 
-enum { SMO_SH23 = 1, SMO_SHB23 = 2, SMO_KDYN = 3 };            /* smo_config.kind */
+enum { SMO_SH23 = 1, SMO_SHB23 = 2, SMO_KDYN = 3, SMO_POIS = 4 }; /* smo_config.kind */
+enum { SMO_POIS_KINETIC = 0, SMO_POIS_MIXNORM = 1 };          /* smo_config.cost (POIS): the reference's switch s, FWD_Solve_Poiseuille.py:1761-1762 */
 enum { SMO_COST_FINAL = 0, SMO_COST_INTEGRATED = 1 };           /* smo_config.cost (KDYN) */
 enum { SMO_SHB_DISCRETE = 0, SMO_SHB_CONTINUOUS = 1 };          /* smo_config.cost (SHB23): formulation, FWD_Solve_SHB23.py:213-217 */
 enum { SMO_ADJ_DISCRETE = 0, SMO_ADJ_CONTINUOUS = 1 };          /* `adjoint_type` argument */
 
 typedef struct smo_config {
-    int    kind;        /* SMO_SH23 | SMO_SHB23 | SMO_KDYN */
+    int    kind;        /* SMO_SH23 | SMO_SHB23 | SMO_KDYN | SMO_POIS */
     int    npts;        /* Npts as the reference's Generate_IC receives it (SH23 256, SHB23 512, KDYN 128) */
     double x0, x1;      /* interval of every axis: SH23 (0,12pi), SHB23 (-20,20), KDYN (0,2pi) */
     double dt;          /* time step */
@@ -71,6 +76,11 @@ typedef struct smo_config {
      * states in between, one window at a time, during the adjoint sweep (+ (ckpt-1)/ckpt forward steps per adjoint step).
      * 1 = keep everything (the reference's N_SUB_ITERS = N_ITERS); 0 = smallest interval whose stack fits the free HBM. */
     int    ckpt;
+    /* second resolution / further parameters (POIS only; zero elsewhere): npts = Nx and npts2 = Nz as FWD_Solve_Discrete receives them
+     * (already scaled by 3/2, FWD_Solve_Poiseuille.py:1752-1755); x0,x1 = the x interval (0, 4 pi), z is (-1, 1); param = Reynolds,
+     * param2 = Richardson, param3 = Prandtl (0 -> 1), param4 = delta of the base density profile (0 -> 0.25); cost = s. */
+    int    npts2;
+    double param2, param3, param4;
 } smo_config;
 
 /* ---- life cycle ------------------------------------------------------------------------------------------- */
@@ -100,12 +110,16 @@ int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double
 
 /* ---- introspection used by the parity tests and the benchmark ------------------------------------------------ */
 /* Copy snapshot `index` (0..n_iters) of batch member `b` to the host in the reference's GEN_BUFFER element order:
- * SH23 complex128[Nc]; SHB23 float64[N]; KDYN complex128[3][a][m][m].  `out` receives smo_snapshot_len doubles. */
+ * SH23 complex128[Nc]; SHB23 float64[N]; KDYN complex128[3][a][m][m]; POIS complex128[3][Nx/2][Nz] (u_fwd, w_fwd, b_fwd of the
+ * non-negative wavenumbers).  `out` receives smo_snapshot_len doubles. */
 int smo_snapshot_len(const smo_ctx* ctx, size_t* ndoubles);
 int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out);
 
-/* The reference's standalone Chebyshev maps (SHB23 only; FWD_Solve_SHB23.py:36-67), host buffers of npts doubles:
- * which = 0 transform (grid->T coefficients), 1 transformInverse, 2 transformAdjoint, 3 transformInverseAdjoint. */
+/* The reference's standalone transforms, host buffers: which = 0 transform (grid -> coefficients), 1 transformInverse,
+ * 2 transformAdjoint (coefficients -> grid), 3 transformInverseAdjoint (grid -> coefficients).
+ *   SHB23 (FWD_Solve_SHB23.py:36-67): npts doubles either way.
+ *   POIS  (FWD_Solve_Poiseuille.py:44-89): grid = float64[Nx][Nz] of a REAL field, coefficients = complex128[a][Nz] for the
+ *          non-negative x wavenumbers n = 0..a-1, a = Nx/2 (the other half of the reference's complex spectrum is the Hermitian mirror). */
 int smo_transform(smo_ctx* ctx, int which, const double* in, double* out);
 
 /* ---- slab-decomposed 3-D case: one process per GPU -------------------------------------

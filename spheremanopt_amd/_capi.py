@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMO_LIB", os.path.join(_HERE, "lib", "libsmo.so"))      # SMO_LIB: experimental builds
 
-SMO_SH23, SMO_SHB23, SMO_KDYN = 1, 2, 3
+SMO_SH23, SMO_SHB23, SMO_KDYN, SMO_POIS = 1, 2, 3, 4
 COST = {"Final": 0, "Integrated": 1}
 ADJOINT = {"Discrete": 0, "Continuous": 1}
 ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO_ERR_STATE", 5: "SMO_ERR_NOMEM",
@@ -34,7 +34,8 @@ class SmoError(RuntimeError):
 class smo_config(C.Structure):
     _fields_ = [("kind", C.c_int), ("npts", C.c_int), ("x0", C.c_double), ("x1", C.c_double), ("dt", C.c_double),
                 ("n_iters", C.c_int), ("param", C.c_double), ("cost", C.c_int), ("batch", C.c_int), ("device", C.c_int),
-                ("rank", C.c_int), ("world", C.c_int), ("ckpt", C.c_int)]
+                ("rank", C.c_int), ("world", C.c_int), ("ckpt", C.c_int),
+                ("npts2", C.c_int), ("param2", C.c_double), ("param3", C.c_double), ("param4", C.c_double)]
 
 
 _lib = None
@@ -122,10 +123,11 @@ def _dev_ptr(t):
 class Context:
     """Owner of one smo_ctx (device buffers, twiddles, the HBM snapshot stack)."""
 
-    def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1, ckpt=1):
+    def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1, ckpt=1,
+                 npts2=0, param2=0., param3=0., param4=0.):
         cfg = smo_config(kind, int(npts), float(interval[0]), float(interval[1]), float(dt), int(n_iters), float(param),
                          COST[cost] if isinstance(cost, str) else int(cost), int(batch), int(device), int(rank), int(world),
-                         int(ckpt))
+                         int(ckpt), int(npts2), float(param2), float(param3), float(param4))
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib().smo_create(C.byref(cfg), C.byref(self._h)))
@@ -205,9 +207,10 @@ class Context:
         _check(lib().smo_snapshot_read(self._h, int(b), int(index), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
-    def transform(self, which, x):
+    def transform(self, which, x, out_len=None):
+        """smo_transform; `out_len` = doubles of the result when it differs from the input (POIS: grid <-> complex coefficients)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
-        out = np.empty_like(x)
+        out = np.empty_like(x) if out_len is None else np.empty(int(out_len))
         _check(lib().smo_transform(self._h, int(which), x.ctypes.data, out.ctypes.data))
         return out
 

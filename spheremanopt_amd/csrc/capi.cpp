@@ -42,6 +42,7 @@ int smo_create(const smo_config* cfg, smo_ctx** out) {
         case SMO_SH23: c = smo::make_sh23(*cfg); break;
         case SMO_SHB23: c = smo::make_shb23(*cfg); break;
         case SMO_KDYN: c = smo::make_kdyn(*cfg); break;
+        case SMO_POIS: c = smo::make_pois(*cfg); break;
         default: smo::set_error("smo_create: unknown kind %d", cfg->kind); return SMO_ERR_ARG;
     }
     if (!c) return SMO_ERR_UNSUPPORTED;      // message set by the factory

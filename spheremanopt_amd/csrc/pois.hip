@@ -1,0 +1,781 @@
+// POIS — stratified plane-Poiseuille optimal mixing (2-D, Fourier in x, Chebyshev in z), "Discrete" formulation.
+//
+// Replaces FWD_Solve_Discrete / ADJ_Solve_Discrete / Inner_Prod_Discrete and the transform helpers of
+// Example_Problems/Bounded_Domain(Cheby)/Optimal_Mixing/FWD_Solve_Poiseuille.py (:777-1155, :1320-1659, :282-299, :44-118).
+//
+// The reference steps an 8-variable Dedalus LBVP per x-wavenumber with SciPy DCTs and hand-written transposed solves.  Here the
+// whole path is cast as dense fp64 matrix products on the matrix cores (v_mfma_f64_16x16x4_f64):
+//   * every transform and its adjoint is a pair of small GEMMs: a z matrix (Nz x Nz: Chebyshev grid <-> T coefficients, with the
+//     z derivative / de-aliasing mask folded in where needed) and an x matrix (Nx x 2a: Hermitian half spectrum <-> real grid, with
+//     d/dx folded in) — the adjoint transforms are the transposed z matrices, so the discrete adjoint is exact by construction;
+//   * the tau solve of the LBVP is the dense map  S_k : (rhs_u, rhs_v, rhs_rho) -> (u, v, rho, uz, vz, rhoz)  per wavenumber
+//     (built once on the host by a banded pivoted LU of the tau system), applied as a batched complex GEMV; the reference's
+//     transposed solve  P^L^H A^-H P^R^H  is S_k^H.
+// Real fields => only the a = Nx/2 non-negative wavenumbers n = 0..kmax are carried (the reference carries the full complex spectrum of
+// a complex-dtype domain, POIS:338; the negative half is the Hermitian mirror).  The forward state lives in the de-aliased modes
+// n < ada = (2Nx/3)/2 only; the adjoint state does not (the reference's transposed solves run on every pencil), so the adjoint carries all.
+//
+// Layouts: coefficient fields [2a][Nz] doubles, row 2n = Re, row 2n+1 = Im of mode n, T index fastest; grid fields [Nx][Nz], z
+// fastest = the reference's flat vectors [u.flatten(), v.flatten()] (POIS:160-207); snapshot stack [n][3][2a][Nz].
+#include <algorithm>
+#include <complex>
+#include <thread>
+
+#include "smo_common.hpp"
+
+namespace smo {
+namespace {
+
+using cd = std::complex<double>;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 64x64 tile per workgroup, 4 waves of 32x32
+// ---------------------------------------------------------------------------------------------------------
+struct GemmDesc { const double* A; const double* B; double* C; };
+
+__global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ descs, int M, int N, int K) {
+    const GemmDesc d = descs[blockIdx.z];
+    __shared__ double As[64][17];
+    __shared__ double Bs[16][65];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            const int ar = idx >> 4, ac = idx & 15;
+            As[ar][ac] = (m0 + ar < M && k0 + ac < K) ? d.A[(size_t)(m0 + ar) * K + k0 + ac] : 0.0;
+            const int br = idx >> 6, bc = idx & 63;
+            Bs[br][bc] = (k0 + br < K && n0 + bc < N) ? d.B[(size_t)(k0 + br) * N + n0 + bc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[wm + 16 * i + lr][kk + lk];       // A[row = lane&15][k = lane>>4]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kk + lk][wn + 16 * j + lr];       // B[k = lane>>4][col = lane&15]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                            // C: col = lane&15, row = (lane>>4) + 4*reg
+                const int row = m0 + wm + 16 * i + lk + 4 * r, col = n0 + wn + 16 * j + lr;
+                if (row < M && col < N) d.C[(size_t)row * N + col] = acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-wavenumber operator apply: out[fo][n] = sum_fi S_n[fo][fi] in[fi][n]  (complex; S_n dense (nout*Nz) x (nin*Nz))
+// one wave per output row; the operator is streamed once (the HBM-bound part of a time step)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S, const double* __restrict__ in, double* __restrict__ out,
+                                                  double* __restrict__ snap, int a, int modes, int Nz, int nin, int nout) {
+    const int lane = threadIdx.x & 63;
+    const int rows = nout * Nz, cols = nin * Nz;
+    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= (long long)modes * rows) return;
+    const int n = (int)(gr / rows), r = (int)(gr - (long long)n * rows);
+    const double2* Srow = S + ((size_t)n * rows + r) * cols;
+    double yr = 0.0, yi = 0.0;
+    for (int c = lane; c < cols; c += 64) {
+        const int fi = c / Nz, j = c - fi * Nz;
+        const double xr = in[((size_t)fi * 2 * a + 2 * n) * Nz + j], xi = in[((size_t)fi * 2 * a + 2 * n + 1) * Nz + j];
+        const double2 s = Srow[c];
+        yr += s.x * xr - s.y * xi;
+        yi += s.x * xi + s.y * xr;
+    }
+    for (int off = 32; off > 0; off >>= 1) { yr += __shfl_down(yr, off); yi += __shfl_down(yi, off); }
+    if (lane == 0) {
+        const int fo = r / Nz, j = r - fo * Nz;
+        const size_t o = ((size_t)fo * 2 * a + 2 * n) * Nz + j;
+        out[o] = yr; out[o + Nz] = yi;
+        if (snap && fo < 3) { snap[o] = yr; snap[o + Nz] = yi; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pointwise kernels (grid fields [Nx][Nz], z fastest; nG = Nx*Nz)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NPART = 256;
+
+__device__ __forceinline__ void block_sum_store(double acc, double* dst) {
+    __shared__ double red[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = red[0] + red[1] + red[2] + red[3];
+}
+
+// forward: g = [u, ux, uz, v, vx, vz, rx, rz] -> nl = [NLu, NLv, NLr] (POIS:911-921); part <- sum W (u^2 + v^2)
+__global__ __launch_bounds__(256) void pois_nl(const double* __restrict__ g, double* __restrict__ nl, const double* __restrict__ Wz,
+                                               double* __restrict__ part, size_t nG, int Nz) {
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nG; i += (size_t)gridDim.x * 256) {
+        const double u = g[i], ux = g[nG + i], uz = g[2 * nG + i], v = g[3 * nG + i], vx = g[4 * nG + i], vz = g[5 * nG + i],
+                     rx = g[6 * nG + i], rz = g[7 * nG + i];
+        nl[i] = -u * ux - v * uz;
+        nl[nG + i] = -u * vx - v * vz;
+        nl[2 * nG + i] = -u * rx - v * rz;
+        acc += Wz[i % Nz] * (u * u + v * v);
+    }
+    block_sum_store(acc, part + blockIdx.x);
+}
+// part <- sum W (p^2 + q^2) of two grid fields;  out0/out1 (optional) <- scale * W * p, scale * W * q
+__global__ __launch_bounds__(256) void pois_wsq(const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ Wz,
+                                                double* __restrict__ part, double* out0, double* out1, double scale, size_t nG, int Nz) {
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nG; i += (size_t)gridDim.x * 256) {
+        const double w = Wz[i % Nz], a = p[i], b = q[i];
+        acc += w * (a * a + b * b);
+        if (out0) { out0[i] = scale * w * a; out1[i] = scale * w * b; }
+    }
+    block_sum_store(acc, part + blockIdx.x);
+}
+// dst = a * x + y over n doubles (y may be null)
+__global__ __launch_bounds__(256) void pois_axpy(double* __restrict__ dst, const double* x, double a, const double* y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = a * x[i] + (y ? y[i] : 0.0);
+}
+// dst (coefficient field) = i k * src  (row 2n: -k Im, row 2n+1: k Re)
+__global__ __launch_bounds__(256) void pois_ik(double* __restrict__ dst, const double* __restrict__ src, double k1, int a, int Nz) {
+    const size_t n = (size_t)a * Nz;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / Nz), j = (int)(i - (size_t)m * Nz);
+        const double k = k1 * m, re = src[((size_t)2 * m) * Nz + j], im = src[((size_t)2 * m + 1) * Nz + j];
+        dst[((size_t)2 * m) * Nz + j] = -k * im;
+        dst[((size_t)2 * m + 1) * Nz + j] = k * re;
+    }
+}
+// adjoint: products of the adjoint grids v1..v3 with the forward state grids (NLtermAdj, POIS:1510-1524) [+ the KE forcing]
+//   in : gr = [v1, v2, v3, u, v, ux, vx, rx, uz, vz, rz]
+//   out: pr = [adju, adjux, adjuz, adjv, adjvx, adjvz, adjrx, adjrz, (fu, fv)]
+__global__ __launch_bounds__(256) void pois_adj_products(const double* __restrict__ gr, double* __restrict__ pr, const double* __restrict__ Wz,
+                                                         double fscale, int forcing, size_t nG, int Nz) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nG; i += (size_t)gridDim.x * 256) {
+        const double v1 = gr[i], v2 = gr[nG + i], v3 = gr[2 * nG + i], u = gr[3 * nG + i], v = gr[4 * nG + i], ux = gr[5 * nG + i],
+                     vx = gr[6 * nG + i], rx = gr[7 * nG + i], uz = gr[8 * nG + i], vz = gr[9 * nG + i], rz = gr[10 * nG + i];
+        pr[i] = -ux * v1 - vx * v2 - rx * v3;
+        pr[nG + i] = -u * v1;
+        pr[2 * nG + i] = -v * v1;
+        pr[3 * nG + i] = -uz * v1 - vz * v2 - rz * v3;
+        pr[4 * nG + i] = -u * v2;
+        pr[5 * nG + i] = -v * v2;
+        pr[6 * nG + i] = -u * v3;
+        pr[7 * nG + i] = -v * v3;
+        if (forcing) { const double w = fscale * Wz[i % Nz]; pr[8 * nG + i] = w * u; pr[9 * nG + i] = w * v; }
+    }
+}
+// adjoint state update (POIS:1624-1634): hc = the ten transformed products, a3 = S^H lambda
+__global__ __launch_bounds__(256) void pois_adj_combine(double* __restrict__ L6, const double* __restrict__ a3, const double* __restrict__ hc,
+                                                        double inv_dt, int forcing, size_t nC) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nC; i += (size_t)gridDim.x * 256) {
+        double lu = a3[i] * inv_dt + hc[i] + hc[nC + i], lv = a3[nC + i] * inv_dt + hc[3 * nC + i] + hc[4 * nC + i];
+        if (forcing) { lu += hc[8 * nC + i]; lv += hc[9 * nC + i]; }
+        L6[i] = lu;
+        L6[nC + i] = lv;
+        L6[2 * nC + i] = a3[2 * nC + i] * inv_dt + hc[6 * nC + i];
+        L6[3 * nC + i] = hc[2 * nC + i];
+        L6[4 * nC + i] = hc[5 * nC + i];
+        L6[5 * nC + i] = hc[7 * nC + i];
+    }
+}
+// grad = (V / W) * g  for the two components
+__global__ __launch_bounds__(256) void pois_grad_out(double* __restrict__ out, const double* __restrict__ g, const double* __restrict__ Wz,
+                                                     double V, size_t n2G, int Nz) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2G; i += (size_t)gridDim.x * 256) out[i] = V / Wz[i % Nz] * g[i];
+}
+__global__ __launch_bounds__(256) void pois_dot(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ Wz,
+                                                double* __restrict__ part, size_t n2G, int Nz) {
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2G; i += (size_t)gridDim.x * 256) acc += Wz[i % Nz] * x[i] * y[i];
+    block_sum_store(acc, part + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host: Chebyshev pieces and the tau systems
+// ---------------------------------------------------------------------------------------------------------
+struct Cheb {
+    int N;
+    std::vector<double> Pre, D, PD, M1, M2, integ;          // dense N x N (row-major); PD = Pre * D
+    explicit Cheb(int n) : N(n), Pre((size_t)n * n, 0.0), D((size_t)n * n, 0.0), PD((size_t)n * n, 0.0), M1((size_t)n * n, 0.0),
+                           M2((size_t)n * n, 0.0), integ(n, 0.0) {
+        for (int i = 0; i < N; ++i) {
+            Pre[(size_t)i * N + i] = i == 0 ? 1.0 : 0.5;
+            if (i + 2 < N) Pre[(size_t)i * N + i + 2] = -0.5;
+            for (int j = i + 1; j < N; ++j) D[(size_t)i * N + j] = ((j - i) & 1) ? (i == 0 ? 1.0 : 2.0) * j : 0.0;
+            integ[i] = (i & 1) ? 0.0 : 2.0 / (1.0 - (double)i * i);
+        }
+        for (int i = 0; i + 1 < N; ++i) PD[(size_t)i * N + i + 1] = i + 1;            // d/dz T_n = n U_{n-1}
+        auto mult = [&](std::vector<double>& M, int j, double fj) {                    // T_j T_m = (T_{m+j} + T_{|m-j|}) / 2
+            for (int m = 0; m < N; ++m) {
+                if (m + j < N) M[(size_t)(m + j) * N + m] += 0.5 * fj;
+                M[(size_t)std::abs(m - j) * N + m] += 0.5 * fj;
+            }
+        };
+        mult(M1, 0, 0.5); mult(M1, 2, -0.5);                                           // 1 - z^2
+        mult(M2, 1, -2.0);                                                             // -2 z
+    }
+    double pre_times(const std::vector<double>& M, int r, int c) const {              // (Pre * M)[r][c]
+        double s = (r == 0 ? 1.0 : 0.5) * M[(size_t)r * N + c];
+        if (r + 2 < N) s -= 0.5 * M[(size_t)(r + 2) * N + c];
+        return s;
+    }
+};
+
+// Solve A X = B (A n x n with structural zeros, B n x m) in place by LU with partial pivoting.  The tau systems are banded (unknowns
+// and equations interleaved by Chebyshev mode) apart from a few dense boundary rows kept at the bottom (rows >= nb): column k can only
+// be non-zero in the `win` rows below the diagonal and in the dense rows, so those are the pivot candidates and the rows to
+// eliminate; a per-row "last non-zero column" bound keeps the row operations inside the (growing) band.
+static int banded_solve(int n, int nb, int win, std::vector<cd>& A, int m, std::vector<cd>& B) {
+    auto at = [&](int r, int c) -> cd& { return A[(size_t)r * n + c]; };
+    std::vector<int> hi(n, 0);
+    for (int r = 0; r < n; ++r)
+        for (int c = n - 1; c >= 0; --c) if (at(r, c) != cd(0)) { hi[r] = c; break; }
+    for (int k = 0; k < n; ++k) {
+        const int wend = std::min(n, k + win), dense0 = std::max(wend, nb);
+        int p = -1; double best = 0.0;
+        auto consider = [&](int r) { const double v = std::abs(at(r, k)); if (v > best) { best = v; p = r; } };
+        for (int r = k; r < wend; ++r) consider(r);
+        for (int r = dense0; r < n; ++r) consider(r);
+        if (p < 0) { set_error("POIS: tau matrix is singular at column %d of %d", k, n); return SMO_ERR_ARG; }
+        if (p != k) {
+            std::swap_ranges(&at(k, 0), &at(k, 0) + n, &at(p, 0));
+            std::swap_ranges(&B[(size_t)k * m], &B[(size_t)k * m] + m, &B[(size_t)p * m]);
+            std::swap(hi[k], hi[p]);
+        }
+        const cd piv = at(k, k);
+        const int hk = hi[k];
+        auto elim = [&](int r) {
+            const cd f = at(r, k);
+            if (f == cd(0)) return;
+            const cd l = f / piv;
+            at(r, k) = 0;
+            cd* ar = &at(r, 0); const cd* ak = &at(k, 0);
+            for (int c = k + 1; c <= hk; ++c) ar[c] -= l * ak[c];
+            cd* br = &B[(size_t)r * m]; const cd* bk = &B[(size_t)k * m];
+            for (int j = 0; j < m; ++j) br[j] -= l * bk[j];
+            hi[r] = std::max(hi[r], hk);
+        };
+        for (int r = k + 1; r < wend; ++r) elim(r);
+        for (int r = std::max(dense0, k + 1); r < n; ++r) elim(r);
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        cd* bk = &B[(size_t)k * m];
+        for (int c = k + 1; c <= hi[k]; ++c) {
+            const cd u = at(k, c);
+            if (u == cd(0)) continue;
+            const cd* bc = &B[(size_t)c * m];
+            for (int j = 0; j < m; ++j) bk[j] -= u * bc[j];
+        }
+        const cd inv = 1.0 / at(k, k);
+        for (int j = 0; j < m; ++j) bk[j] *= inv;
+    }
+    return SMO_OK;
+}
+
+// S_n (6N x 3N) of the momentum / density LBVP (POIS:818-841) for native wavenumber n (k = n * k1).
+// Unknown index 7*mode + var (var: u v rho uz vz rhoz p) [+ Fb at the end for n = 0]; rows: for mode m < N-1 the seven equations
+// (three tau-reduced evolution equations, continuity, three tau-reduced derivative definitions), then continuity of mode N-1, the
+// six boundary / gauge rows [and integ(rho) = 0 for n = 0].
+static int build_solve_map(const Cheb& ch, int n, double k, double a0, double Re, double Pe, double Ri, std::vector<cd>& S) {
+    const int N = ch.N, nv = 7 * N + (n == 0 ? 1 : 0), nb = 7 * (N - 1);
+    std::vector<cd> A((size_t)nv * nv, cd(0)), B((size_t)nv * 3 * N, cd(0));
+    auto at = [&](int r, int c) -> cd& { return A[(size_t)r * nv + c]; };
+    enum { U = 0, V = 1, R = 2, UZ = 3, VZ = 4, RZ = 5, P = 6 };
+    const cd ik(0.0, k);
+    for (int m = 0; m < N - 1; ++m) {
+        const int r0 = 7 * m;
+        for (int c = std::max(0, m - 2); c < std::min(N, m + 5); ++c) {
+            const double pre = ch.Pre[(size_t)m * N + c], pm1 = ch.pre_times(ch.M1, m, c), pm2 = ch.pre_times(ch.M2, m, c),
+                         pd = ch.PD[(size_t)m * N + c];
+            at(r0 + 0, 7 * c + U) += (a0 + k * k / Re) * pre + ik * pm1;  at(r0 + 0, 7 * c + UZ) += -pd / Re;
+            at(r0 + 0, 7 * c + P) += ik * pre;                            at(r0 + 0, 7 * c + V) += pm2;
+            at(r0 + 1, 7 * c + V) += (a0 + k * k / Re) * pre + ik * pm1;  at(r0 + 1, 7 * c + VZ) += -pd / Re;
+            at(r0 + 1, 7 * c + P) += pd;                                  at(r0 + 1, 7 * c + R) += Ri * pre;
+            at(r0 + 2, 7 * c + R) += (a0 + k * k / Pe) * pre + ik * pm1;  at(r0 + 2, 7 * c + RZ) += -pd / Pe;
+            at(r0 + 4, 7 * c + UZ) += pre;  at(r0 + 4, 7 * c + U) += -pd;
+            at(r0 + 5, 7 * c + VZ) += pre;  at(r0 + 5, 7 * c + V) += -pd;
+            at(r0 + 6, 7 * c + RZ) += pre;  at(r0 + 6, 7 * c + R) += -pd;
+            for (int e = 0; e < 3; ++e) B[(size_t)(r0 + e) * 3 * N + e * N + c] = pre;
+        }
+        if (n == 0) at(r0 + 2, 7 * N) += ch.Pre[(size_t)m * N + 0];                   // + Fb (constant = its T0 coefficient)
+        at(r0 + 3, 7 * m + U) += ik;  at(r0 + 3, 7 * m + VZ) += 1.0;                   // dx(u) + vz = 0
+    }
+    int row = nb;
+    at(row, 7 * (N - 1) + U) += ik;  at(row, 7 * (N - 1) + VZ) += 1.0;  ++row;
+    auto functional = [&](int var, int kind) {                                         // 0 left, 1 right, 2 integ
+        for (int j = 0; j < N; ++j) at(row, 7 * j + var) = kind == 0 ? ((j & 1) ? -1.0 : 1.0) : (kind == 1 ? 1.0 : ch.integ[j]);
+        ++row;
+    };
+    functional(U, 0); functional(V, 0); functional(U, 1);
+    if (n != 0) functional(V, 1); else functional(P, 2);
+    functional(RZ, 0); functional(RZ, 1);
+    if (n == 0) functional(R, 2);
+    SMO_TRY(banded_solve(nv, nb, 7 * 6, A, 3 * N, B));
+    S.assign((size_t)6 * N * 3 * N, cd(0));
+    for (int var = 0; var < 6; ++var)
+        for (int j = 0; j < N; ++j) std::copy(&B[(size_t)(7 * j + var) * 3 * N], &B[(size_t)(7 * j + var) * 3 * N] + 3 * N, &S[((size_t)var * N + j) * 3 * N]);
+    return SMO_OK;
+}
+// S^MN_n (2N x N): rho -> (psi, psiz),  dx dx psi + dz psiz + F = rho,  psiz = dz psi,  psiz(+-1) = 0,  integ psi = 0 at n = 0
+static int build_mixnorm_map(const Cheb& ch, int n, double k, std::vector<cd>& S) {
+    const int N = ch.N, nv = 2 * N + (n == 0 ? 1 : 0), nb = 2 * (N - 1);
+    std::vector<cd> A((size_t)nv * nv, cd(0)), B((size_t)nv * N, cd(0));
+    auto at = [&](int r, int c) -> cd& { return A[(size_t)r * nv + c]; };
+    for (int m = 0; m < N - 1; ++m) {
+        for (int c = m; c < std::min(N, m + 3); ++c) {
+            const double pre = ch.Pre[(size_t)m * N + c], pd = ch.PD[(size_t)m * N + c];
+            at(2 * m, 2 * c) += -k * k * pre;  at(2 * m, 2 * c + 1) += pd;
+            at(2 * m + 1, 2 * c + 1) += pre;   at(2 * m + 1, 2 * c) += -pd;
+            B[(size_t)(2 * m) * N + c] = pre;
+        }
+        if (n == 0) at(2 * m, 2 * N) += ch.Pre[(size_t)m * N + 0];
+    }
+    for (int j = 0; j < N; ++j) { at(nb, 2 * j + 1) = (j & 1) ? -1.0 : 1.0; at(nb + 1, 2 * j + 1) = 1.0; }
+    if (n == 0) for (int j = 0; j < N; ++j) at(nb + 2, 2 * j) = ch.integ[j];
+    SMO_TRY(banded_solve(nv, nb, 2 * 4, A, N, B));
+    S.assign((size_t)2 * N * N, cd(0));
+    for (int var = 0; var < 2; ++var)
+        for (int j = 0; j < N; ++j) std::copy(&B[(size_t)(2 * j + var) * N], &B[(size_t)(2 * j + var) * N] + N, &S[((size_t)var * N + j) * N]);
+    return SMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------
+class Pois : public Context {
+public:
+    explicit Pois(const smo_config& c) { cfg = c; }
+    int Nx = 0, Nz = 0, a = 0, ada = 0, Nz0 = 0, s_cost = 0;      // a: modes carried (n = 0..kmax); ada: de-aliased modes (n < ada)
+    double Lx = 0, k1 = 0, V = 0, Re = 0, Ri = 0, Pe = 0, delta = 0;
+    size_t nC = 0, nG = 0;
+    // matrices
+    double *B_ZiT = nullptr, *B_DZiT = nullptr, *B_ZfT = nullptr, *B_ZfT_DA = nullptr, *B_Zf = nullptr, *B_Zf_DA = nullptr, *B_Zi = nullptr,
+           *B_ZiDz = nullptr, *B_DzT = nullptr, *B_Dz = nullptr;
+    double *A_Xi = nullptr, *A_XiD = nullptr, *A_XiN = nullptr, *A_XiN_DA = nullptr, *A_Xf = nullptr, *A_Xf_DA = nullptr, *A_XfN = nullptr, *A_XfNDa = nullptr;
+    double *d_Wz = nullptr, *d_rho0 = nullptr, *d_rz0 = nullptr;
+    double2 *d_S = nullptr, *d_SH = nullptr, *d_SMN = nullptr, *d_SMNH = nullptr;
+    // work
+    double *S6 = nullptr, *R3 = nullptr, *L6 = nullptr, *A3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr,
+           *HC = nullptr, *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
+    std::vector<double> h_part;
+    int k_gemm = -1, k_apply = -1, k_point = -1;
+
+    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
+    Phase F0x, F0z, F0d, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Az, Ax, Axf, Azf, Gd, Gz, Gx;
+
+    int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
+        p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
+        return pool.upload(&p.d, v, stream);
+    }
+    int run(const Phase& p, int count = -1) {
+        const int n = count < 0 ? p.n : count;
+        ScopedTimer t(timing, k_gemm, stream);
+        hipLaunchKernelGGL(pois_gemm, dim3((p.N + 63) / 64, (p.M + 63) / 64, n), dim3(256), 0, stream, p.d, p.M, p.N, p.K);
+        return SMO_OK;
+    }
+    // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
+    int apply(const double2* S, const double* in, double* out, double* snap, int nin, int nout, int modes) {
+        const long long rows = (long long)modes * nout * Nz;
+        ScopedTimer t(timing, k_apply, stream);
+        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, out, snap, a, modes, Nz, nin, nout);
+        return SMO_OK;
+    }
+    dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
+    double* snap(int n) { return d_stack + (size_t)n * 3 * nC; }
+
+    int init() override {
+        Nx = cfg.npts; Nz = cfg.npts2; s_cost = cfg.cost;
+        if (cfg.batch != 1 || cfg.world != 1) { set_error("POIS: batch and world must be 1"); return SMO_ERR_ARG; }
+        if (Nx < 12 || Nz < 12 || Nx > 768 || Nz > 384 || Nx % 6 != 0 || Nz % 3 != 0) {
+            set_error("POIS: need npts (Nx) a multiple of 6 in [12, 768] and npts2 (Nz) a multiple of 3 in [12, 384], got %d x %d", Nx, Nz);
+            return SMO_ERR_UNSUPPORTED;
+        }
+        if (s_cost != 0 && s_cost != 1) { set_error("POIS: cost must be 0 (time-averaged kinetic energy) or 1 (mix-norm)"); return SMO_ERR_ARG; }
+        Lx = cfg.x1 - cfg.x0; k1 = 2.0 * M_PI / Lx; V = Lx * 2.0;
+        Re = cfg.param; Ri = cfg.param2; Pe = cfg.param * (cfg.param3 > 0 ? cfg.param3 : 1.0); delta = cfg.param4 > 0 ? cfg.param4 : 0.25;
+        a = (Nx - 1) / 2 + 1; ada = (2 * Nx / 3) / 2; Nz0 = 2 * Nz / 3;
+        nC = (size_t)2 * a * Nz; nG = (size_t)Nx * Nz;
+        n_comp = 1;
+        vec_len = 2 * nG;
+        snapshot_doubles = 3 * nC;
+        stack_bytes = (size_t)(cfg.n_iters + 1) * 3 * nC * sizeof(double);
+        SMO_TRY(base_init());
+        const int N = Nz;
+        // ---- z matrices -----------------------------------------------------------------------------------------------
+        std::vector<double> Tf((size_t)N * N), Ti((size_t)N * N), Dz((size_t)N * N, 0.0), z(N), Wz(N);
+        for (int i = 0; i < N; ++i) z[i] = -std::cos(M_PI * (i + 0.5) / N);
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < N; ++i) {
+                const double c = std::cos(M_PI * j * (2 * i + 1) / (2.0 * N)), sg = (j & 1) ? -1.0 : 1.0;
+                Tf[(size_t)j * N + i] = (2.0 / N) * c * (j == 0 ? 0.5 : 1.0) * sg;          // transform (POIS:44-51)
+                Ti[(size_t)i * N + j] = sg * c;                                              // transformInverse (POIS:67-76)
+            }
+        Cheb ch(N);
+        Dz = ch.D;
+        Wz[0] = z[1] - z[0];
+        for (int i = 1; i < N; ++i) Wz[i] = z[i] - z[i - 1];
+        const double dx = Lx / Nx;
+        for (int i = 0; i < N; ++i) Wz[i] *= dx;                                              // weightMatrixDisc (POIS:91-118)
+        auto T = [&](const std::vector<double>& Mx) { std::vector<double> t((size_t)N * N); for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) t[(size_t)j * N + i] = Mx[(size_t)i * N + j]; return t; };
+        auto mul = [&](const std::vector<double>& X, const std::vector<double>& Y) {
+            std::vector<double> Zm((size_t)N * N, 0.0);
+            for (int i = 0; i < N; ++i) for (int m = 0; m < N; ++m) { const double x = X[(size_t)i * N + m]; if (x != 0.0) for (int j = 0; j < N; ++j) Zm[(size_t)i * N + j] += x * Y[(size_t)m * N + j]; }
+            return Zm;
+        };
+        auto mask_cols = [&](std::vector<double> Mx) { for (int i = 0; i < N; ++i) for (int j = Nz0; j < N; ++j) Mx[(size_t)i * N + j] = 0.0; return Mx; };
+        auto mask_rows = [&](std::vector<double> Mx) { for (int i = Nz0; i < N; ++i) for (int j = 0; j < N; ++j) Mx[(size_t)i * N + j] = 0.0; return Mx; };
+        const std::vector<double> TiDz = mul(Ti, Dz);
+        SMO_TRY(pool.upload(&B_ZiT, T(Ti), stream));           // [j][z] = Ti[z][j]
+        SMO_TRY(pool.upload(&B_DZiT, T(TiDz), stream));        // [j][z] = (Ti Dz)[z][j]
+        SMO_TRY(pool.upload(&B_ZfT, T(Tf), stream));           // [z][j] = Tf[j][z]
+        SMO_TRY(pool.upload(&B_ZfT_DA, mask_cols(T(Tf)), stream));
+        SMO_TRY(pool.upload(&B_Zf, Tf, stream));               // [j][z]: transformAdjoint z part
+        SMO_TRY(pool.upload(&B_Zf_DA, mask_rows(Tf), stream));
+        SMO_TRY(pool.upload(&B_Zi, Ti, stream));               // [z][j]: transformInverseAdjoint z part
+        SMO_TRY(pool.upload(&B_ZiDz, TiDz, stream));
+        SMO_TRY(pool.upload(&B_DzT, T(Dz), stream));           // c @ Dz^T
+        SMO_TRY(pool.upload(&B_Dz, Dz, stream));               // c @ Dz
+        SMO_TRY(pool.upload(&d_Wz, Wz, stream));
+        // ---- x matrices (Hermitian half spectrum n = 0..a-1, rows/cols 2n = Re, 2n+1 = Im) --------------------------------------
+        std::vector<double> Xi((size_t)Nx * 2 * a), XiD(Xi.size()), XiN(Xi.size()), Xf((size_t)2 * a * Nx), XfN(Xf.size()), XfNDa(Xf.size());
+        for (int x = 0; x < Nx; ++x)
+            for (int n = 0; n < a; ++n) {
+                const double k = k1 * n, ph = 2.0 * M_PI * (double)((long long)n * x % Nx) / Nx, c = std::cos(ph), sn = std::sin(ph), w = n == 0 ? 1.0 : 2.0;
+                Xi[(size_t)x * 2 * a + 2 * n] = w * c;             Xi[(size_t)x * 2 * a + 2 * n + 1] = -w * sn;
+                XiD[(size_t)x * 2 * a + 2 * n] = -w * k * sn;      XiD[(size_t)x * 2 * a + 2 * n + 1] = -w * k * c;
+                XiN[(size_t)x * 2 * a + 2 * n] = w * c / Nx;       XiN[(size_t)x * 2 * a + 2 * n + 1] = -w * sn / Nx;
+                Xf[(size_t)(2 * n) * Nx + x] = c / Nx;             Xf[(size_t)(2 * n + 1) * Nx + x] = -sn / Nx;
+                XfN[(size_t)(2 * n) * Nx + x] = c;                 XfN[(size_t)(2 * n + 1) * Nx + x] = -sn;
+                XfNDa[(size_t)(2 * n) * Nx + x] = -k * sn;         XfNDa[(size_t)(2 * n + 1) * Nx + x] = -k * c;
+            }
+        SMO_TRY(pool.upload(&A_Xi, Xi, stream)); SMO_TRY(pool.upload(&A_XiD, XiD, stream)); SMO_TRY(pool.upload(&A_XiN, XiN, stream));
+        SMO_TRY(pool.upload(&A_Xf, Xf, stream)); SMO_TRY(pool.upload(&A_XfN, XfN, stream)); SMO_TRY(pool.upload(&A_XfNDa, XfNDa, stream));
+        for (int x = 0; x < Nx; ++x) for (int c = 2 * ada; c < 2 * a; ++c) XiN[(size_t)x * 2 * a + c] = 0.0;     // de-aliasing mask in x
+        for (int r = 2 * ada; r < 2 * a; ++r) for (int x = 0; x < Nx; ++x) Xf[(size_t)r * Nx + x] = 0.0;
+        SMO_TRY(pool.upload(&A_XiN_DA, XiN, stream)); SMO_TRY(pool.upload(&A_Xf_DA, Xf, stream));
+        // ---- base state rho = -erf(z/delta)/2 (n = 0 only), de-aliased (POIS:932-936) ------------------------------------------------
+        {
+            std::vector<double> r0(nC, 0.0), rz0(nC, 0.0);
+            for (int j = 0; j < Nz0; ++j) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int i = 0; i < N; ++i) {
+                    s0 += Tf[(size_t)j * N + i] * (-0.5 * std::erf(z[i] / delta));
+                    s1 += Tf[(size_t)j * N + i] * (-std::exp(-(z[i] / delta) * (z[i] / delta)) / (delta * std::sqrt(M_PI)));
+                }
+                r0[j] = s0; rz0[j] = s1;
+            }
+            SMO_TRY(pool.upload(&d_rho0, r0, stream)); SMO_TRY(pool.upload(&d_rz0, rz0, stream));
+        }
+        // ---- tau operators, one per wavenumber, built by host threads ---------------------------------------------------------------------
+        {
+            const size_t sz = (size_t)6 * N * 3 * N, szm = (size_t)2 * N * N;
+            std::vector<cd> S((size_t)a * sz), SH((size_t)a * sz), SM((size_t)a * szm), SMH((size_t)a * szm);
+            std::vector<int> rc(a, SMO_OK);
+            std::vector<std::string> msg(a);
+            const int nthr = std::max(1, std::min<int>(a, (int)std::thread::hardware_concurrency()));
+            auto work = [&](int t) {
+                for (int n = t; n < a; n += nthr) {
+                    std::vector<cd> s, sm;
+                    int r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, s);
+                    if (r == SMO_OK) r = build_mixnorm_map(ch, n, k1 * n, sm);
+                    if (r != SMO_OK) { rc[n] = r; msg[n] = last_error(); continue; }
+                    std::copy(s.begin(), s.end(), S.begin() + (size_t)n * sz);
+                    std::copy(sm.begin(), sm.end(), SM.begin() + (size_t)n * szm);
+                    for (int i = 0; i < 6 * N; ++i) for (int j = 0; j < 3 * N; ++j) SH[(size_t)n * sz + (size_t)j * 6 * N + i] = std::conj(s[(size_t)i * 3 * N + j]);
+                    for (int i = 0; i < 2 * N; ++i) for (int j = 0; j < N; ++j) SMH[(size_t)n * szm + (size_t)j * 2 * N + i] = std::conj(sm[(size_t)i * N + j]);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+            for (auto& t : th) t.join();
+            for (int n = 0; n < a; ++n) if (rc[n] != SMO_OK) { set_error("%s (wavenumber %d)", msg[n].c_str(), n); return rc[n]; }
+            auto up = [&](double2** p, const std::vector<cd>& h) -> int {
+                SMO_TRY(pool.alloc(p, h.size()));
+                SMO_HIP(hipMemcpyAsync(*p, h.data(), h.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+                SMO_HIP(hipStreamSynchronize(stream));
+                return SMO_OK;
+            };
+            SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SH, SH)); SMO_TRY(up(&d_SMN, SM)); SMO_TRY(up(&d_SMNH, SMH));
+        }
+        // ---- work buffers -----------------------------------------------------------------------------------------------
+        SMO_TRY(pool.alloc(&S6, 6 * nC)); SMO_TRY(pool.alloc(&R3, 3 * nC)); SMO_TRY(pool.alloc(&L6, 6 * nC)); SMO_TRY(pool.alloc(&A3, 3 * nC));
+        SMO_TRY(pool.alloc(&cur3, 3 * nC)); SMO_TRY(pool.alloc(&G1, 9 * nC)); SMO_TRY(pool.alloc(&GR, 11 * nG)); SMO_TRY(pool.alloc(&PR, 10 * nG));
+        SMO_TRY(pool.alloc(&H, 10 * nC)); SMO_TRY(pool.alloc(&HC, 10 * nC)); SMO_TRY(pool.alloc(&MN, 2 * nC));
+        SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nC));
+        SMO_HIP(hipMemsetAsync(d_stack, 0, (size_t)(cfg.n_iters + 1) * 3 * nC * sizeof(double), stream));    // rows n >= ada stay zero
+        SMO_TRY(pool.alloc(&d_part, (size_t)(cfg.n_iters + 2) * NPART));
+        h_part.resize((size_t)(cfg.n_iters + 2) * NPART);
+        SMO_HIP(hipMemsetAsync(d_part, 0, (size_t)(cfg.n_iters + 2) * NPART * sizeof(double), stream));
+        // ---- GEMM phases -----------------------------------------------------------------------------------------------
+        const int M2a = 2 * a;
+        auto c_ = [&](double* base, int i) { return base + (size_t)i * nC; };
+        auto g_ = [&](double* base, int i) { return base + (size_t)i * nG; };
+        // forward set-up: X (copied to GR[0..1]) -> u, v (de-aliased), uz, vz
+        SMO_TRY(make_phase(F0x, M2a, Nz, Nx, {{A_Xf_DA, g_(GR, 0), c_(H, 0)}, {A_Xf_DA, g_(GR, 1), c_(H, 1)}}));
+        SMO_TRY(make_phase(F0z, M2a, Nz, Nz, {{c_(H, 0), B_ZfT_DA, c_(S6, 0)}, {c_(H, 1), B_ZfT_DA, c_(S6, 1)}}));
+        SMO_TRY(make_phase(F0d, M2a, Nz, Nz, {{c_(S6, 0), B_DzT, c_(S6, 3)}, {c_(S6, 1), B_DzT, c_(S6, 4)}}));
+        // forward step
+        { std::vector<GemmDesc> v; for (int f = 0; f < 6; ++f) v.push_back({c_(S6, f), B_ZiT, c_(G1, f)}); SMO_TRY(make_phase(Fz, M2a, Nz, Nz, v)); }
+        SMO_TRY(make_phase(Fx, Nx, Nz, M2a, {{A_Xi, c_(G1, 0), g_(GR, 0)}, {A_XiD, c_(G1, 0), g_(GR, 1)}, {A_Xi, c_(G1, 3), g_(GR, 2)},
+                                             {A_Xi, c_(G1, 1), g_(GR, 3)}, {A_XiD, c_(G1, 1), g_(GR, 4)}, {A_Xi, c_(G1, 4), g_(GR, 5)},
+                                             {A_XiD, c_(G1, 2), g_(GR, 6)}, {A_Xi, c_(G1, 5), g_(GR, 7)}}));
+        { std::vector<GemmDesc> v, w; for (int f = 0; f < 3; ++f) { v.push_back({A_Xf_DA, g_(PR, f), c_(H, f)}); w.push_back({c_(H, f), B_ZfT_DA, c_(HC, f)}); }
+          SMO_TRY(make_phase(Fxf, M2a, Nz, Nx, v)); SMO_TRY(make_phase(Fzf, M2a, Nz, Nz, w)); }
+        // mix-norm fields psi (cur3[2]) and psiz (cur3[1]) -> grids gx = dx psi, gz = psiz
+        SMO_TRY(make_phase(M1z, M2a, Nz, Nz, {{c_(cur3, 2), B_ZiT, c_(G1, 0)}, {c_(cur3, 1), B_ZiT, c_(G1, 1)}}));
+        SMO_TRY(make_phase(M1x, Nx, Nz, M2a, {{A_XiD, c_(G1, 0), g_(GR, 0)}, {A_Xi, c_(G1, 1), g_(GR, 1)}}));
+        // adjoint terminal conditions
+        SMO_TRY(make_phase(T0z, M2a, Nz, Nz, {{c_(cur3, 0), B_ZiT, c_(G1, 0)}, {c_(cur3, 1), B_ZiT, c_(G1, 1)}}));
+        SMO_TRY(make_phase(T0x, Nx, Nz, M2a, {{A_Xi, c_(G1, 0), g_(GR, 0)}, {A_Xi, c_(G1, 1), g_(GR, 1)}}));
+        SMO_TRY(make_phase(T0xf, M2a, Nz, Nx, {{A_XfN, g_(PR, 0), c_(H, 0)}, {A_XfN, g_(PR, 1), c_(H, 1)}}));
+        SMO_TRY(make_phase(T0zf, M2a, Nz, Nz, {{c_(H, 0), B_Zi, c_(L6, 0)}, {c_(H, 1), B_Zi, c_(L6, 1)}}));
+        SMO_TRY(make_phase(T1xf, M2a, Nz, Nx, {{A_XfNDa, g_(PR, 0), c_(H, 0)}, {A_XfN, g_(PR, 1), c_(H, 1)}}));
+        SMO_TRY(make_phase(T1zf, M2a, Nz, Nz, {{c_(H, 0), B_Zi, c_(HC, 0)}, {c_(H, 1), B_ZiDz, c_(HC, 1)}}));
+        // adjoint step
+        { std::vector<GemmDesc> v;
+          for (int f = 0; f < 3; ++f) v.push_back({c_(A3, f), B_Zf_DA, c_(G1, f)});
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_ZiT, c_(G1, 3 + f)});
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_DZiT, c_(G1, 6 + f)});
+          SMO_TRY(make_phase(Az, M2a, Nz, Nz, v)); }
+        SMO_TRY(make_phase(Ax, Nx, Nz, M2a, {{A_XiN_DA, c_(G1, 0), g_(GR, 0)}, {A_XiN_DA, c_(G1, 1), g_(GR, 1)}, {A_XiN_DA, c_(G1, 2), g_(GR, 2)},
+                                             {A_Xi, c_(G1, 3), g_(GR, 3)}, {A_Xi, c_(G1, 4), g_(GR, 4)}, {A_XiD, c_(G1, 3), g_(GR, 5)},
+                                             {A_XiD, c_(G1, 4), g_(GR, 6)}, {A_XiD, c_(G1, 5), g_(GR, 7)}, {A_Xi, c_(G1, 6), g_(GR, 8)},
+                                             {A_Xi, c_(G1, 7), g_(GR, 9)}, {A_Xi, c_(G1, 8), g_(GR, 10)}}));
+        { std::vector<GemmDesc> v, w;
+          for (int i = 0; i < 10; ++i) { v.push_back({(i == 1 || i == 4 || i == 6) ? A_XfNDa : A_XfN, g_(PR, i), c_(H, i)}); w.push_back({c_(H, i), B_Zi, c_(HC, i)}); }
+          SMO_TRY(make_phase(Axf, M2a, Nz, Nx, v)); SMO_TRY(make_phase(Azf, M2a, Nz, Nz, w)); }
+        // gradient output
+        SMO_TRY(make_phase(Gd, M2a, Nz, Nz, {{c_(L6, 3), B_Dz, c_(HC, 0)}, {c_(L6, 4), B_Dz, c_(HC, 1)}}));
+        SMO_TRY(make_phase(Gz, M2a, Nz, Nz, {{c_(L6, 0), B_Zf, c_(G1, 0)}, {c_(L6, 1), B_Zf, c_(G1, 1)}}));
+        SMO_TRY(make_phase(Gx, Nx, Nz, M2a, {{A_XiN, c_(G1, 0), g_(GR, 0)}, {A_XiN, c_(G1, 1), g_(GR, 1)}}));
+        const double op_bytes = (double)a * 6 * N * 3 * N * 16.0;
+        k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
+        k_apply = timing.add_class("pois_apply (tau operator, batched complex GEMV)", op_bytes);
+        k_point = timing.add_class("pois pointwise", 0.0);
+        return SMO_OK;
+    }
+
+    int sum_partials(int row0, int nrows, double* out) {               // out[r] = sum of row r's NPART partials
+        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part + (size_t)row0 * NPART, (size_t)nrows * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        for (int r = 0; r < nrows; ++r) { double s = 0.0; for (int i = 0; i < NPART; ++i) s += h_part[(size_t)r * NPART + i]; out[r] = s; }
+        return SMO_OK;
+    }
+    int state_grids() { SMO_TRY(run(Fz)); return run(Fx); }
+    int nl_and_energy(int step) {
+        ScopedTimer t(timing, k_point, stream);
+        hipLaunchKernelGGL(pois_nl, dim3(NPART), dim3(256), 0, stream, GR, PR, d_Wz, d_part + (size_t)step * NPART, nG, Nz);
+        return SMO_OK;
+    }
+
+    int forward_dev(const double* const* X, double* J) override {
+        have_forward = false;
+        const int N = cfg.n_iters;
+        SMO_HIP(hipMemcpyAsync(GR, X[0], 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipMemsetAsync(S6, 0, 6 * nC * sizeof(double), stream));
+        SMO_TRY(run(F0x)); SMO_TRY(run(F0z)); SMO_TRY(run(F0d));
+        SMO_HIP(hipMemcpyAsync(S6 + 2 * nC, d_rho0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_rz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipMemcpyAsync(snap(0), S6, 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        for (int n = 0; n < N; ++n) {
+            SMO_TRY(state_grids());
+            SMO_TRY(nl_and_energy(n));
+            SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, S6, 1.0 / cfg.dt, HC, 3 * nC);
+            }
+            SMO_TRY(apply(d_S, R3, S6, snap(n + 1), 3, 6, ada));
+        }
+        double cost = 0.0;
+        if (s_cost == 1) {
+            // mix-norm (POIS:1053-1124): (psi, psiz) = S^MN rho_N; snapshot N holds (dx psi, psiz, psi); cost = <grad psi, grad psi> / 2
+            SMO_TRY(apply(d_SMN, S6 + 2 * nC, MN, nullptr, 1, 2, a));
+            SMO_HIP(hipMemcpyAsync(cur3 + 2 * nC, MN, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_HIP(hipMemcpyAsync(cur3 + nC, MN + nC, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_ik, pw_grid((size_t)a * Nz), dim3(256), 0, stream, cur3, MN, k1, a, Nz);
+            }
+            SMO_HIP(hipMemcpyAsync(snap(N), cur3, 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_TRY(run(M1z)); SMO_TRY(run(M1x));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_wsq, dim3(NPART), dim3(256), 0, stream, GR, GR + nG, d_Wz, d_part + (size_t)(N + 1) * NPART, (double*)nullptr,
+                                   (double*)nullptr, 0.0, nG, Nz);
+            }
+            double e = 0.0;
+            SMO_TRY(sum_partials(N + 1, 1, &e));
+            cost = 0.5 * e / V;
+        } else {
+            SMO_TRY(state_grids());
+            SMO_TRY(nl_and_energy(N));
+            std::vector<double> e(N + 1);
+            SMO_TRY(sum_partials(0, N + 1, e.data()));
+            double ke = 0.0;
+            for (int n = 0; n <= N; ++n) ke += cfg.dt * e[n] / V;
+            cost = -0.5 * ke;
+        }
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        *J = cost;
+        have_forward = true;
+        return SMO_OK;
+    }
+
+    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        if (adjoint_type != SMO_ADJ_DISCRETE) { set_error("POIS: only the Discrete formulation is built"); return SMO_ERR_UNSUPPORTED; }
+        const int N = cfg.n_iters;
+        const bool forcing = s_cost == 0;
+        SMO_HIP(hipMemsetAsync(L6, 0, 6 * nC * sizeof(double), stream));
+        SMO_HIP(hipMemcpyAsync(cur3, snap(N), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (s_cost == 1) {
+            SMO_TRY(run(M1z)); SMO_TRY(run(M1x));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_wsq, dim3(NPART), dim3(256), 0, stream, GR, GR + nG, d_Wz, d_part + (size_t)(N + 1) * NPART, PR, PR + nG, 1.0 / V, nG, Nz);
+            }
+            SMO_TRY(run(T1xf)); SMO_TRY(run(T1zf));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_axpy, pw_grid(nC), dim3(256), 0, stream, MN, HC, 1.0, HC + nC, nC);
+            }
+            SMO_HIP(hipMemsetAsync(MN + nC, 0, nC * sizeof(double), stream));
+            SMO_TRY(apply(d_SMNH, MN, L6 + 2 * nC, nullptr, 2, 1, a));
+        } else {
+            SMO_TRY(run(T0z)); SMO_TRY(run(T0x));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_wsq, dim3(NPART), dim3(256), 0, stream, GR, GR + nG, d_Wz, d_part + (size_t)(N + 1) * NPART, PR, PR + nG, -cfg.dt / V, nG, Nz);
+            }
+            SMO_TRY(run(T0xf)); SMO_TRY(run(T0zf));
+        }
+        for (int idx = N - 1; idx >= 0; --idx) {
+            SMO_TRY(apply(d_SH, L6, A3, nullptr, 6, 3, a));
+            SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_TRY(run(Az)); SMO_TRY(run(Ax));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_adj_products, pw_grid(nG), dim3(256), 0, stream, GR, PR, d_Wz, -cfg.dt / V, forcing ? 1 : 0, nG, Nz);
+            }
+            const int np = forcing ? 10 : 8;
+            SMO_TRY(run(Axf, np)); SMO_TRY(run(Azf, np));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_adj_combine, pw_grid(nC), dim3(256), 0, stream, L6, A3, HC, 1.0 / cfg.dt, forcing ? 1 : 0, nC);
+            }
+        }
+        SMO_TRY(run(Gd));
+        {
+            ScopedTimer t(timing, k_point, stream);
+            hipLaunchKernelGGL(pois_axpy, pw_grid(2 * nC), dim3(256), 0, stream, L6, L6, 1.0, HC, 2 * nC);
+        }
+        SMO_TRY(run(Gz)); SMO_TRY(run(Gx));
+        {
+            ScopedTimer t(timing, k_point, stream);
+            hipLaunchKernelGGL(pois_grad_out, pw_grid(2 * nG), dim3(256), 0, stream, grad[0], GR, d_Wz, V, 2 * nG, Nz);
+        }
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
+    int inner_dev(const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(pois_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_Wz, d_part + (size_t)(cfg.n_iters + 1) * NPART, 2 * nG, Nz);
+        SMO_HIP(hipGetLastError());
+        double s = 0.0;
+        SMO_TRY(sum_partials(cfg.n_iters + 1, 1, &s));
+        *out = s / V;
+        return SMO_OK;
+    }
+
+    // internal [2a][Nz] rows (Re, Im) <-> the reference's complex128 [a][Nz]
+    void to_complex(const std::vector<double>& rows, double* out, int nf) const {
+        for (int f = 0; f < nf; ++f)
+            for (int n = 0; n < a; ++n)
+                for (int j = 0; j < Nz; ++j) {
+                    out[(((size_t)f * a + n) * Nz + j) * 2] = rows[(size_t)f * nC + ((size_t)2 * n) * Nz + j];
+                    out[(((size_t)f * a + n) * Nz + j) * 2 + 1] = rows[(size_t)f * nC + ((size_t)2 * n + 1) * Nz + j];
+                }
+    }
+    int snapshot_read(int, int index, double* out) override {
+        std::vector<double> h(3 * nC);
+        SMO_HIP(hipMemcpyAsync(h.data(), snap(index), 3 * nC * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        to_complex(h, out, 3);
+        return SMO_OK;
+    }
+
+    // the reference's four transforms on ONE real field / Hermitian coefficient array (POIS:44-89), host buffers:
+    //   0 transform: grid [Nx][Nz] -> complex [a][Nz];  1 transformInverse: complex -> grid;
+    //   2 transformAdjoint: complex -> grid;            3 transformInverseAdjoint: grid -> complex
+    int transform_host(int which, const double* in, double* out) override {
+        if (which < 0 || which > 3) { set_error("smo_transform: which = %d", which); return SMO_ERR_ARG; }
+        const bool to_coeff = (which == 0 || which == 3);
+        GemmDesc h1, h2;
+        if (to_coeff) {
+            SMO_HIP(hipMemcpyAsync(GR, in, nG * sizeof(double), hipMemcpyHostToDevice, stream));
+            h1 = {which == 0 ? A_Xf : A_XfN, GR, H};
+            h2 = {H, which == 0 ? B_ZfT : B_Zi, HC};
+        } else {
+            std::vector<double> rows(nC);
+            for (int n = 0; n < a; ++n)
+                for (int j = 0; j < Nz; ++j) { rows[((size_t)2 * n) * Nz + j] = in[((size_t)n * Nz + j) * 2]; rows[((size_t)2 * n + 1) * Nz + j] = in[((size_t)n * Nz + j) * 2 + 1]; }
+            SMO_HIP(hipMemcpyAsync(H, rows.data(), nC * sizeof(double), hipMemcpyHostToDevice, stream));
+            SMO_HIP(hipStreamSynchronize(stream));
+            h1 = {H, which == 1 ? B_ZiT : B_Zf, G1};
+            h2 = {which == 1 ? A_Xi : A_XiN, G1, GR};
+        }
+        GemmDesc* d = nullptr;
+        SMO_HIP(hipMalloc(&d, 2 * sizeof(GemmDesc)));
+        const GemmDesc hd[2] = {h1, h2};
+        hipError_t e = hipMemcpyAsync(d, hd, sizeof(hd), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            const int M2a = 2 * a;
+            if (to_coeff) {
+                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d, M2a, Nz, Nx);
+                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d + 1, M2a, Nz, Nz);
+            } else {
+                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d, M2a, Nz, Nz);
+                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (Nx + 63) / 64, 1), dim3(256), 0, stream, d + 1, Nx, Nz, M2a);
+            }
+            e = hipStreamSynchronize(stream);
+        }
+        (void)hipFree(d);
+        if (e != hipSuccess) { set_error("smo_transform: %s", hipGetErrorString(e)); return SMO_ERR_HIP; }
+        if (to_coeff) {
+            std::vector<double> rows(nC);
+            SMO_HIP(hipMemcpyAsync(rows.data(), HC, nC * sizeof(double), hipMemcpyDeviceToHost, stream));
+            SMO_HIP(hipStreamSynchronize(stream));
+            to_complex(rows, out, 1);
+        } else {
+            SMO_HIP(hipMemcpyAsync(out, GR, nG * sizeof(double), hipMemcpyDeviceToHost, stream));
+            SMO_HIP(hipStreamSynchronize(stream));
+        }
+        return SMO_OK;
+    }
+};
+
+}  // namespace
+
+Context* make_pois(const smo_config& cfg) { return new Pois(cfg); }
+
+}  // namespace smo

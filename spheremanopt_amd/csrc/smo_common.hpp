@@ -158,5 +158,6 @@ protected:
 Context* make_sh23(const smo_config& cfg);
 Context* make_shb23(const smo_config& cfg);
 Context* make_kdyn(const smo_config& cfg);
+Context* make_pois(const smo_config& cfg);
 
 }  // namespace smo

@@ -1,0 +1,80 @@
+"""Plane-Poiseuille optimal mixing on the device (through the C-ABI) against the oracle: the four transforms (dense MFMA GEMMs),
+the tau-operator time stepping, both cost functionals and the exact discrete adjoint (1e-6 relative on J and grad J)."""
+import numpy as np
+import pytest
+
+from spheremanopt_amd import _capi, poiseuille as pz
+from spheremanopt_amd.test_grad import taylor_table
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def hermitian_full(o, c):
+    """(a, Nz) coefficients of the non-negative wavenumbers -> the reference's full complex spectrum (Nxc, Nz) of a REAL field."""
+    full = np.zeros((o.Nxc, o.Nz), dtype=complex)
+    for i, n in enumerate(o.n):
+        full[i] = c[n] if n >= 0 else np.conj(c[-n])
+    full[0] = full[0].real
+    return full
+
+
+@pytest.mark.parametrize("Nx,Nz", [(24, 24), (48, 36), (30, 66)])
+def test_transforms_match_oracle(Nx, Nz):
+    from oracle.poiseuille import PoiseuilleOracle
+    o = PoiseuilleOracle(Nx, Nz)
+    dom = pz.PoiseuilleDomain(Nx, Nz)
+    rs = np.random.RandomState(1)
+    g = rs.standard_normal((Nx, Nz))
+    c = rs.standard_normal((o.ax, Nz)) + 1j * rs.standard_normal((o.ax, Nz))
+    cf = hermitian_full(o, c)
+    assert rel(pz.transform(g, dom), o.transform(g)[:o.ax]) < 1e-12
+    assert rel(pz.transformInverseAdjoint(g, dom), o.transformInverseAdjoint(g)[:o.ax]) < 1e-12
+    assert rel(pz.transformInverse(c, dom), o.transformInverse(cf).real) < 1e-12
+    assert rel(pz.transformAdjoint(c, dom), o.transformAdjoint(cf).real) < 1e-12
+    assert np.abs(o.transformInverse(cf).imag).max() < 1e-12
+    dom.drop_contexts()
+
+
+@pytest.mark.parametrize("Nx,Nz,n,s", [(24, 24, 6, 0), (24, 24, 6, 1), (48, 36, 10, 0), (36, 48, 8, 1), (96, 48, 4, 0)])
+def test_forward_adjoint_vs_oracle(Nx, Nz, n, s):
+    from oracle.poiseuille import PoiseuilleOracle, synthetic_ic
+    o = PoiseuilleOracle(Nx, Nz, dt=5e-3, N_ITERS=n, s=s, delta=0.3)
+    X = synthetic_ic(o, 42)
+    dom = pz.PoiseuilleDomain(Nx, Nz)
+    buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+    args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.3]
+    J = pz.FWD_Solve_Discrete([X], *args)
+    g = pz.ADJ_Solve_Discrete([X], *args)
+    Jo = o.forward([X]); go = o.adjoint([X])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert len(g) == 1 and g[0].shape == X.shape and rel(g[0], go[0]) < RTOL, rel(g[0], go[0])
+    for f, key in enumerate(('u_fwd', 'w_fwd', 'b_fwd')):
+        for i in (0, 1, -2, -1):
+            assert rel(buf[key][:, :, i], o.stack[f, :o.ax, :, i]) < 1e-8, (key, i)
+    ip = o.inner(X, go[0])
+    assert abs(pz.Inner_Prod_Discrete(X, g[0], dom) - ip) <= RTOL * abs(ip)
+    assert np.array_equal(pz.weightMatrixDisc(dom), o.W)
+    dom.drop_contexts()
+
+
+def test_taylor_ic_and_errors():
+    dom, U0 = pz.Generate_IC(48, 36, E_0=0.02, seed=42)
+    _, dU0 = pz.Generate_IC(48, 36, E_0=0.02, seed=7)
+    assert abs(pz.Inner_Prod(U0[0], U0[0], dom) - 0.02) < 1e-14
+    u = U0[0][:48 * 36].reshape(48, 36)
+    c = pz.transform(u, dom)                                     # de-aliased like the reference's prepared IC (u['c'] *= DA, POIS:608)
+    assert np.abs(c[dom.ada:]).max() < 1e-12 * np.abs(c).max() and np.abs(c[:, 24:]).max() < 1e-12 * np.abs(c).max()
+    buf = pz.GEN_BUFFER(48, 36, dom, 10)
+    args_f = [dom, 500., 0.05, 10, buf, 5e-3, 0, 1., 0.3]
+    AA = taylor_table(U0, dU0, pz.FWD_Solve, pz.ADJ_Solve, pz.Inner_Prod, args_f, [dom, None], epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 2e-2), AA
+    with pytest.raises(_capi.SmoError):
+        dom.context(500., 0.05, 10, 5e-3, 0, 1., 0.3).adjoint(None, "Continuous")
+    with pytest.raises(_capi.SmoError):
+        pz.PoiseuilleDomain(50, 36).any_context()
+    dom.drop_contexts()
