@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=None, help="sh23 | shb23 | kdyn (default: the largest single-GPU config built)")
+    ap.add_argument("--workload", default=None, help="sh23 | shb23 | kdyn | pois (default: kdyn, the largest single-GPU config of BASELINE.json)")
     ap.add_argument("--npts", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None, help="override N_ITERS (the result is then flagged as reduced)")
     ap.add_argument("--batch", type=int, default=1)
@@ -141,6 +141,47 @@ def bench_shb23(a, torch, rank, world):
         cpu = {"value": n / (time.perf_counter() - t0), "unit": "gradient evals/s", "cores": 1, "kind": "port",
                "sample": "%d full forward+adjoint evaluations of the same workload (NumPy restatement)" % n}
     return steps, warm, el, a.batch, roof, cfg, cpu
+
+
+def bench_pois(a, torch, rank, world):
+    """Plane-Poiseuille optimal mixing at the reference script's resolution (FWD_Solve_Poiseuille.py:1746-1762): a 'next' row of SURVEY 8f."""
+    from spheremanopt_amd import poiseuille as pz
+    Nx, Nz = 384, 192                                   # 3/2 * (256, 128)
+    dt, n_iters = 5e-3, a.iters or 1000
+    steps = a.steps if a.steps is not None else 3
+    warm = a.warmup if a.warmup is not None else 1
+    t0 = time.perf_counter()
+    dom = pz.PoiseuilleDomain(Nx, Nz, device=torch.cuda.current_device())
+    ctx = dom.context(500., 0.05, n_iters, dt, 1, 1., 0.125)
+    build_s = time.perf_counter() - t0
+    X = 1e-3 * np.random.RandomState(42 + rank).standard_normal(2 * Nx * Nz)
+    Xd = torch.from_numpy(X).cuda()
+    Gd = torch.empty_like(Xd)
+    for _ in range(warm):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    tim = ctx.timing()
+    dom_k = max(tim, key=lambda t: t["total_ms"])
+    avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
+            "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1)} for t in tim],
+            "note": "bytes_per_launch = the tau operators of the de-aliased wavenumbers (forward apply); the adjoint apply streams 1.5x that"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    cfg = {"workload": "Plane-Poiseuille optimal mixing (Discrete), Nx x Nz = %d x %d, Re=500, Ri=0.05, T=%g, dt=%g, mix-norm cost"
+                       % (Nx, Nz, dt * n_iters, dt),
+           "grid": [Nx, Nz], "n_iters": n_iters, "operator_build_s": build_s, "parallelism": "replicas only (x%d)" % world}
+    return steps, warm, el, 1, roof, cfg, None
 
 
 def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
@@ -320,6 +361,8 @@ def main():
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
     elif wl == "shb23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_shb23(a, torch, rank, world)
+    elif wl == "pois":
+        steps, warm, el, per_step_units, roof, cfg, cpu = bench_pois(a, torch, rank, world)
     elif wl == "kdyn" and world > 1 and not a.replicas:
         try:
             steps, warm, el, per_step_units, roof, cfg, cpu, scaling = bench_kdyn_slab(a, torch, rank, world)
@@ -338,11 +381,12 @@ def main():
     if world == 1 and a.workload is None and not a.no_secondary:
         # the two latency-bound 1-D configs of BASELINE.json (configs[1], configs[2]) ride along as secondary lines
         secondary = []
-        for fn, kw in ((bench_sh23, dict(steps=50, warmup=5)), (bench_shb23, dict(steps=10, warmup=2))):
+        for fn, kw in ((bench_sh23, dict(steps=50, warmup=5)), (bench_shb23, dict(steps=10, warmup=2)), (bench_pois, dict(steps=2, warmup=1))):
             b = argparse.Namespace(**{**vars(a), "npts": None, "iters": None, "batch": 1, "no_cpu_baseline": True, **kw})
             st, wm, e2, units, rf, cf, _ = fn(b, torch, rank, world)
             secondary.append({"workload": cf["workload"], "value": st * units / e2, "unit": "gradient evals/s", "ms_per_step": 1e3 * e2 / st,
-                              "us_per_time_step": rf["avg_launch_ms"] * 1e3 / cf["n_iters"], "steps": st, "warmup": wm})
+                              "us_per_time_step": (1e6 * e2 / st / (2 * cf["n_iters"])) if fn is bench_pois else rf["avg_launch_ms"] * 1e3 / cf["n_iters"],
+                              "steps": st, "warmup": wm})
     if world > 1:
         t = torch.tensor([el], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         scaling = scaling if "slab" in cfg.get("parallelism", "") else "weak"

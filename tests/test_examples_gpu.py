@@ -40,3 +40,15 @@ def test_sh23_and_shb23_scripts(in_tmp_cwd):
     R, F, X, AA = shb23_optimise.main(["--npts", "256", "--T", "2", "--max-iters", "3", "--test-gradient", "--quiet"])
     assert np.all(np.abs(AA[4, :4] - 2.0) < 1e-2), AA
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
+
+
+def test_poiseuille_script(in_tmp_cwd):
+    """FWD_Solve_Poiseuille.py's __main__ (Discrete formulation) at a reduced resolution: Taylor test with the kinetic-energy cost, then
+    a few CG/Wolfe iterations with the mix-norm cost (the reference's default, s = 1); the cost must not increase."""
+    from spheremanopt_amd.examples import poiseuille_optimise
+    R, F, X, AA = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.1", "--s", "0", "--max-iters", "3", "--test-gradient", "--quiet"])
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 2e-2), AA
+    assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
+    R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "1", "--max-iters", "3", "--quiet"])
+    assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
+    assert len(X) == 1 and X[0].shape == (2 * 48 * 36,)

@@ -135,6 +135,31 @@ def test_shb23_continuous_adjoint_is_first_order_consistent():
     assert abs(o.stack[:, -1].sum()) < 1e-12
 
 
+def test_poiseuille_transform_adjoints_and_taylor():
+    """Plane-Poiseuille oracle: the four transforms are adjoint pairs; the time-averaged-energy gradient passes the Taylor test; the
+    mix-norm gradient (whose finite differences sit at round-off for a short run) agrees with a central difference."""
+    from oracle.poiseuille import PoiseuilleOracle, synthetic_ic
+    o = PoiseuilleOracle(24, 36, dt=5e-3, N_ITERS=5, s=0, delta=0.3)
+    rs = np.random.RandomState(0)
+    g = rs.standard_normal((o.Nx, o.Nz)) + 1j * rs.standard_normal((o.Nx, o.Nz))
+    c = rs.standard_normal((o.Nxc, o.Nz)) + 1j * rs.standard_normal((o.Nxc, o.Nz))
+    assert abs(np.vdot(c, o.transform(g)) - np.vdot(o.transformAdjoint(c), g)) < 1e-12
+    assert abs(np.vdot(g, o.transformInverse(c)) - np.vdot(o.transformInverseAdjoint(g), c)) < 1e-10
+    assert np.abs(o.transform(o.transformInverse(c)) - c).max() < 1e-12
+    X = synthetic_ic(o, 42); dX = synthetic_ic(o, 7)
+    assert abs(o.inner(X, X) - 0.02) < 1e-15
+    AA = taylor_table([X], [dX], o.forward, o.adjoint, o.inner, epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 1e-2), AA
+    # every state satisfies the no-slip walls: sum_n u_n = sum_n (-1)^n u_n = 0 for every x wavenumber
+    u = o.stack[0, :, :, -1]
+    assert np.abs(u.sum(axis=1)).max() < 1e-12 and np.abs((u * (-1.) ** np.arange(o.Nz)).sum(axis=1)).max() < 1e-12
+    o1 = PoiseuilleOracle(24, 36, dt=5e-3, N_ITERS=5, s=1, delta=0.3)
+    o1.forward([X])
+    d = o1.inner(o1.adjoint([X])[0], dX)
+    fd = (o1.forward([X + 1e-2 * dX]) - o1.forward([X - 1e-2 * dX])) / 2e-2
+    assert abs(d - fd) < 2e-3 * abs(fd), (d, fd)
+
+
 def test_kdyn_invariants():
     k = KDynOracle(12, Rm=1., dt=1e-2, N_ITERS=5)
     B = synthetic_field(k.G, 1); U = synthetic_field(k.G, 2)
