@@ -30,14 +30,16 @@ using cd = std::complex<double>;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------
-// batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 64x64 tile per workgroup, 4 waves of 32x32
+// batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 64x64 tile per workgroup, 4 waves of 32x32,
+// 32-deep K slices staged through LDS with the next slice prefetched into registers
 // ---------------------------------------------------------------------------------------------------------
 struct GemmDesc { const double* A; const double* B; double* C; };
 
 __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ descs, int M, int N, int K) {
+    constexpr int KT = 32;                                   // K slice per LDS stage
     const GemmDesc d = descs[blockIdx.z];
-    __shared__ double As[64][17];
-    __shared__ double Bs[16][65];
+    __shared__ double As[64][KT + 1];
+    __shared__ double Bs[KT][65];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -47,18 +49,30 @@ __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ de
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    // the next slice is fetched into registers while the current one is multiplied (the launches are small: latency, not bandwidth)
+    double ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
-            const int ar = idx >> 4, ac = idx & 15;
-            As[ar][ac] = (m0 + ar < M && k0 + ac < K) ? d.A[(size_t)(m0 + ar) * K + k0 + ac] : 0.0;
+            const int ar = idx / KT, ac = idx % KT;
+            ra[i] = (m0 + ar < M && k0 + ac < K) ? d.A[(size_t)(m0 + ar) * K + k0 + ac] : 0.0;
             const int br = idx >> 6, bc = idx & 63;
-            Bs[br][bc] = (k0 + br < K && n0 + bc < N) ? d.B[(size_t)(k0 + br) * N + n0 + bc] : 0.0;
+            rb[i] = (k0 + br < K && n0 + bc < N) ? d.B[(size_t)(k0 + br) * N + n0 + bc] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            As[idx / KT][idx % KT] = ra[i];
+            Bs[idx >> 6][idx & 63] = rb[i];
         }
         __syncthreads();
+        if (k0 + KT < K) fetch(k0 + KT);
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 4) {
+        for (int kk = 0; kk < KT; kk += 4) {
             double a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = As[wm + 16 * i + lr][kk + lk];       // A[row = lane&15][k = lane>>4]
@@ -83,32 +97,65 @@ __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ de
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// per-wavenumber operator apply: out[fo][n] = sum_fi S_n[fo][fi] in[fi][n]  (complex; S_n dense (nout*Nz) x (nin*Nz))
-// one wave per output row; the operator is streamed once (the HBM-bound part of a time step)
+// per-wavenumber operator apply: [out fields ; out extras]_n = S_n [in fields ; in extras]_n   (complex)
+//   S_n dense (nout*Nz + xout) x (nin*Nz + xin); fields are [f][2a][Nz] coefficient arrays, extras [2a][3] (row 2n = Re, 2n+1 = Im).
+// One wave per output row; the operators are streamed once: this is the HBM-bound part of a time step.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S, const double* __restrict__ in, double* __restrict__ out,
-                                                  double* __restrict__ snap, int a, int modes, int Nz, int nin, int nout) {
+__global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S, const double* __restrict__ in, const double* __restrict__ xin_v,
+                                                  double* __restrict__ out, double* __restrict__ xout_v, double* __restrict__ snap, int a, int modes,
+                                                  int Nz, int nin, int xin, int nout, int xout) {
     const int lane = threadIdx.x & 63;
-    const int rows = nout * Nz, cols = nin * Nz;
+    const int rows = nout * Nz + xout, cols = nin * Nz + xin, fcols = nin * Nz;
     const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gr >= (long long)modes * rows) return;
     const int n = (int)(gr / rows), r = (int)(gr - (long long)n * rows);
     const double2* Srow = S + ((size_t)n * rows + r) * cols;
     double yr = 0.0, yi = 0.0;
     for (int c = lane; c < cols; c += 64) {
-        const int fi = c / Nz, j = c - fi * Nz;
-        const double xr = in[((size_t)fi * 2 * a + 2 * n) * Nz + j], xi = in[((size_t)fi * 2 * a + 2 * n + 1) * Nz + j];
+        double xr, xi;
+        if (c < fcols) {
+            const int fi = c / Nz, j = c - fi * Nz;
+            xr = in[((size_t)fi * 2 * a + 2 * n) * Nz + j]; xi = in[((size_t)fi * 2 * a + 2 * n + 1) * Nz + j];
+        } else {
+            xr = xin_v[(size_t)(2 * n) * 3 + (c - fcols)]; xi = xin_v[(size_t)(2 * n + 1) * 3 + (c - fcols)];
+        }
         const double2 s = Srow[c];
         yr += s.x * xr - s.y * xi;
         yi += s.x * xi + s.y * xr;
     }
     for (int off = 32; off > 0; off >>= 1) { yr += __shfl_down(yr, off); yi += __shfl_down(yi, off); }
     if (lane == 0) {
-        const int fo = r / Nz, j = r - fo * Nz;
-        const size_t o = ((size_t)fo * 2 * a + 2 * n) * Nz + j;
-        out[o] = yr; out[o + Nz] = yi;
-        if (snap && fo < 3) { snap[o] = yr; snap[o + Nz] = yi; }
+        if (r < nout * Nz) {
+            const int fo = r / Nz, j = r - fo * Nz;
+            const size_t o = ((size_t)fo * 2 * a + 2 * n) * Nz + j;
+            out[o] = yr; out[o + Nz] = yi;
+            if (snap && fo < 3) { snap[o] = yr; snap[o + Nz] = yi; }
+        } else {
+            xout_v[(size_t)(2 * n) * 3 + (r - nout * Nz)] = yr; xout_v[(size_t)(2 * n + 1) * 3 + (r - nout * Nz)] = yi;
+        }
     }
+}
+// The z-derivative variables of the tau system differ from the T-space derivative of u, v, rho only along q = Pre^-1 e_{N-1}
+// (their defining equations hold in all rows but the dropped one):  uz = u Dz^T + uz_{N-1} q.  Only the LAST row of the operator
+// block of each derivative variable is therefore stored (the "extras" of pois_apply): half the operator bytes.
+//   forward : dst[f][r][j] += x[r][f] * q[j]                       (dst = the three derivative fields, already holding u Dz^T etc.)
+__global__ __launch_bounds__(256) void pois_rank1_add(double* __restrict__ dst, const double* __restrict__ x, const double* __restrict__ q, int rows, int Nz) {
+    const size_t n = (size_t)3 * rows * Nz;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i % Nz), r = (int)((i / Nz) % rows), f = (int)(i / ((size_t)rows * Nz));
+        dst[i] += x[(size_t)r * 3 + f] * q[j];
+    }
+}
+//   adjoint : x[r][f] = sum_j q[j] * src[f][r][j]                  (one wave per (f, r))
+__global__ __launch_bounds__(256) void pois_rank1_dot(double* __restrict__ x, const double* __restrict__ src, const double* __restrict__ q, int rows, int Nz) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= 3LL * rows) return;
+    const int f = (int)(w / rows), r = (int)(w - (long long)f * rows);
+    double acc = 0.0;
+    for (int j = lane; j < Nz; j += 64) acc += q[j] * src[((size_t)f * rows + r) * Nz + j];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) x[(size_t)r * 3 + f] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -371,7 +418,8 @@ public:
            *B_ZiDz = nullptr, *B_DzT = nullptr, *B_Dz = nullptr;
     double *A_Xi = nullptr, *A_XiD = nullptr, *A_XiN = nullptr, *A_XiN_DA = nullptr, *A_Xf = nullptr, *A_Xf_DA = nullptr, *A_XfN = nullptr, *A_XfNDa = nullptr;
     double *d_Wz = nullptr, *d_rho0 = nullptr, *d_rz0 = nullptr;
-    double2 *d_S = nullptr, *d_SH = nullptr, *d_SMN = nullptr, *d_SMNH = nullptr;
+    double2 *d_S = nullptr, *d_SH = nullptr, *d_SMN = nullptr, *d_SMNH = nullptr;   // d_S: (3Nz+3) x 3Nz per wavenumber, d_SH its conjugate transpose
+    double *d_q = nullptr, *d_X3 = nullptr;                                         // q = Pre^-1 e_{N-1} (q_{N-1} = 1); extras [2a][3]
     // work
     double *S6 = nullptr, *R3 = nullptr, *L6 = nullptr, *A3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr,
            *HC = nullptr, *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
@@ -379,7 +427,7 @@ public:
     int k_gemm = -1, k_apply = -1, k_point = -1;
 
     struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
-    Phase F0x, F0z, F0d, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Az, Ax, Axf, Azf, Gd, Gz, Gx;
+    Phase F0x, F0z, F0d, F1d, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
 
     int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
         p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
@@ -392,10 +440,12 @@ public:
         return SMO_OK;
     }
     // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
-    int apply(const double2* S, const double* in, double* out, double* snap, int nin, int nout, int modes) {
-        const long long rows = (long long)modes * nout * Nz;
+    int apply(const double2* S, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int nin, int xin, int nout,
+              int xout, int modes) {
+        const long long rows = (long long)modes * (nout * Nz + xout);
         ScopedTimer t(timing, k_apply, stream);
-        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, out, snap, a, modes, Nz, nin, nout);
+        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, xin_v, out, xout_v, snap, a, modes, Nz, nin, xin,
+                           nout, xout);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
@@ -454,6 +504,12 @@ public:
         SMO_TRY(pool.upload(&B_DzT, T(Dz), stream));           // c @ Dz^T
         SMO_TRY(pool.upload(&B_Dz, Dz, stream));               // c @ Dz
         SMO_TRY(pool.upload(&d_Wz, Wz, stream));
+        {
+            std::vector<double> q(N, 0.0);                         // Pre q = e_{N-1} / 2:  q_j = 1 for j = N-1, N-3, ... >= 1; q_0 = 1/2 if it is hit
+            for (int j = N - 1; j >= 1; j -= 2) q[j] = 1.0;
+            if ((N - 1) % 2 == 0) q[0] = 0.5;
+            SMO_TRY(pool.upload(&d_q, q, stream));
+        }
         // ---- x matrices (Hermitian half spectrum n = 0..a-1, rows/cols 2n = Re, 2n+1 = Im) --------------------------------------
         std::vector<double> Xi((size_t)Nx * 2 * a), XiD(Xi.size()), XiN(Xi.size()), Xf((size_t)2 * a * Nx), XfN(Xf.size()), XfNDa(Xf.size());
         for (int x = 0; x < Nx; ++x)
@@ -486,7 +542,7 @@ public:
         }
         // ---- tau operators, one per wavenumber, built by host threads ---------------------------------------------------------------------
         {
-            const size_t sz = (size_t)6 * N * 3 * N, szm = (size_t)2 * N * N;
+            const size_t sz = (size_t)(3 * N + 3) * 3 * N, szm = (size_t)2 * N * N;
             std::vector<cd> S((size_t)a * sz), SH((size_t)a * sz), SM((size_t)a * szm), SMH((size_t)a * szm);
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
@@ -497,9 +553,12 @@ public:
                     int r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, s);
                     if (r == SMO_OK) r = build_mixnorm_map(ch, n, k1 * n, sm);
                     if (r != SMO_OK) { rc[n] = r; msg[n] = last_error(); continue; }
-                    std::copy(s.begin(), s.end(), S.begin() + (size_t)n * sz);
+                    // keep the rows of u, v, rho and the last row of each derivative variable (see pois_rank1_add)
+                    cd* dst = &S[(size_t)n * sz];
+                    std::copy(s.begin(), s.begin() + (size_t)3 * N * 3 * N, dst);
+                    for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * 3 * N], &s[((size_t)(3 + f) * N + N - 1) * 3 * N] + 3 * N, dst + (size_t)(3 * N + f) * 3 * N);
                     std::copy(sm.begin(), sm.end(), SM.begin() + (size_t)n * szm);
-                    for (int i = 0; i < 6 * N; ++i) for (int j = 0; j < 3 * N; ++j) SH[(size_t)n * sz + (size_t)j * 6 * N + i] = std::conj(s[(size_t)i * 3 * N + j]);
+                    for (int i = 0; i < 3 * N + 3; ++i) for (int j = 0; j < 3 * N; ++j) SH[(size_t)n * sz + (size_t)j * (3 * N + 3) + i] = std::conj(dst[(size_t)i * 3 * N + j]);
                     for (int i = 0; i < 2 * N; ++i) for (int j = 0; j < N; ++j) SMH[(size_t)n * szm + (size_t)j * 2 * N + i] = std::conj(sm[(size_t)i * N + j]);
                 }
             };
@@ -518,7 +577,7 @@ public:
         // ---- work buffers -----------------------------------------------------------------------------------------------
         SMO_TRY(pool.alloc(&S6, 6 * nC)); SMO_TRY(pool.alloc(&R3, 3 * nC)); SMO_TRY(pool.alloc(&L6, 6 * nC)); SMO_TRY(pool.alloc(&A3, 3 * nC));
         SMO_TRY(pool.alloc(&cur3, 3 * nC)); SMO_TRY(pool.alloc(&G1, 9 * nC)); SMO_TRY(pool.alloc(&GR, 11 * nG)); SMO_TRY(pool.alloc(&PR, 10 * nG));
-        SMO_TRY(pool.alloc(&H, 10 * nC)); SMO_TRY(pool.alloc(&HC, 10 * nC)); SMO_TRY(pool.alloc(&MN, 2 * nC));
+        SMO_TRY(pool.alloc(&H, 10 * nC)); SMO_TRY(pool.alloc(&HC, 10 * nC)); SMO_TRY(pool.alloc(&MN, 2 * nC)); SMO_TRY(pool.alloc(&d_X3, (size_t)2 * a * 3));
         SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nC));
         SMO_HIP(hipMemsetAsync(d_stack, 0, (size_t)(cfg.n_iters + 1) * 3 * nC * sizeof(double), stream));    // rows n >= ada stay zero
         SMO_TRY(pool.alloc(&d_part, (size_t)(cfg.n_iters + 2) * NPART));
@@ -532,6 +591,8 @@ public:
         SMO_TRY(make_phase(F0x, M2a, Nz, Nx, {{A_Xf_DA, g_(GR, 0), c_(H, 0)}, {A_Xf_DA, g_(GR, 1), c_(H, 1)}}));
         SMO_TRY(make_phase(F0z, M2a, Nz, Nz, {{c_(H, 0), B_ZfT_DA, c_(S6, 0)}, {c_(H, 1), B_ZfT_DA, c_(S6, 1)}}));
         SMO_TRY(make_phase(F0d, M2a, Nz, Nz, {{c_(S6, 0), B_DzT, c_(S6, 3)}, {c_(S6, 1), B_DzT, c_(S6, 4)}}));
+        { std::vector<GemmDesc> v, w; for (int f = 0; f < 3; ++f) { v.push_back({c_(S6, f), B_DzT, c_(S6, 3 + f)}); w.push_back({c_(L6, 3 + f), B_Dz, c_(HC, f)}); }
+          SMO_TRY(make_phase(F1d, M2a, Nz, Nz, v)); SMO_TRY(make_phase(Ad, M2a, Nz, Nz, w)); }
         // forward step
         { std::vector<GemmDesc> v; for (int f = 0; f < 6; ++f) v.push_back({c_(S6, f), B_ZiT, c_(G1, f)}); SMO_TRY(make_phase(Fz, M2a, Nz, Nz, v)); }
         SMO_TRY(make_phase(Fx, Nx, Nz, M2a, {{A_Xi, c_(G1, 0), g_(GR, 0)}, {A_XiD, c_(G1, 0), g_(GR, 1)}, {A_Xi, c_(G1, 3), g_(GR, 2)},
@@ -566,7 +627,7 @@ public:
         SMO_TRY(make_phase(Gd, M2a, Nz, Nz, {{c_(L6, 3), B_Dz, c_(HC, 0)}, {c_(L6, 4), B_Dz, c_(HC, 1)}}));
         SMO_TRY(make_phase(Gz, M2a, Nz, Nz, {{c_(L6, 0), B_Zf, c_(G1, 0)}, {c_(L6, 1), B_Zf, c_(G1, 1)}}));
         SMO_TRY(make_phase(Gx, Nx, Nz, M2a, {{A_XiN, c_(G1, 0), g_(GR, 0)}, {A_XiN, c_(G1, 1), g_(GR, 1)}}));
-        const double op_bytes = (double)a * 6 * N * 3 * N * 16.0;
+        const double op_bytes = (double)ada * (3 * N + 3) * 3 * N * 16.0;
         k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
         k_apply = timing.add_class("pois_apply (tau operator, batched complex GEMV)", op_bytes);
         k_point = timing.add_class("pois pointwise", 0.0);
@@ -591,6 +652,7 @@ public:
         const int N = cfg.n_iters;
         SMO_HIP(hipMemcpyAsync(GR, X[0], 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemsetAsync(S6, 0, 6 * nC * sizeof(double), stream));
+        SMO_HIP(hipMemsetAsync(d_X3, 0, (size_t)2 * a * 3 * sizeof(double), stream));      // rows of the modes n >= ada stay zero
         SMO_TRY(run(F0x)); SMO_TRY(run(F0z)); SMO_TRY(run(F0d));
         SMO_HIP(hipMemcpyAsync(S6 + 2 * nC, d_rho0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_rz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -603,12 +665,17 @@ public:
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, S6, 1.0 / cfg.dt, HC, 3 * nC);
             }
-            SMO_TRY(apply(d_S, R3, S6, snap(n + 1), 3, 6, ada));
+            SMO_TRY(apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada));
+            SMO_TRY(run(F1d));                                               // uz, vz, rhoz = (u, v, rho) Dz^T + last coefficient * q
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_rank1_add, pw_grid(3 * nC), dim3(256), 0, stream, S6 + 3 * nC, d_X3, d_q, 2 * a, Nz);
+            }
         }
         double cost = 0.0;
         if (s_cost == 1) {
             // mix-norm (POIS:1053-1124): (psi, psiz) = S^MN rho_N; snapshot N holds (dx psi, psiz, psi); cost = <grad psi, grad psi> / 2
-            SMO_TRY(apply(d_SMN, S6 + 2 * nC, MN, nullptr, 1, 2, a));
+            SMO_TRY(apply(d_SMN, S6 + 2 * nC, nullptr, MN, nullptr, nullptr, 1, 0, 2, 0, a));
             SMO_HIP(hipMemcpyAsync(cur3 + 2 * nC, MN, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
             SMO_HIP(hipMemcpyAsync(cur3 + nC, MN + nC, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
             {
@@ -659,7 +726,7 @@ public:
                 hipLaunchKernelGGL(pois_axpy, pw_grid(nC), dim3(256), 0, stream, MN, HC, 1.0, HC + nC, nC);
             }
             SMO_HIP(hipMemsetAsync(MN + nC, 0, nC * sizeof(double), stream));
-            SMO_TRY(apply(d_SMNH, MN, L6 + 2 * nC, nullptr, 2, 1, a));
+            SMO_TRY(apply(d_SMNH, MN, nullptr, L6 + 2 * nC, nullptr, nullptr, 2, 0, 1, 0, a));
         } else {
             SMO_TRY(run(T0z)); SMO_TRY(run(T0x));
             {
@@ -669,7 +736,14 @@ public:
             SMO_TRY(run(T0xf)); SMO_TRY(run(T0zf));
         }
         for (int idx = N - 1; idx >= 0; --idx) {
-            SMO_TRY(apply(d_SH, L6, A3, nullptr, 6, 3, a));
+            // S^H lambda with the reduced operator: lambda_{u,v,rho} + lambda_{uz,vz,rhoz} Dz, and the three scalars q . lambda_z
+            SMO_TRY(run(Ad));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
+                hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, L6, 1.0, HC, 3 * nC);
+            }
+            SMO_TRY(apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a));
             SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
             SMO_TRY(run(Az)); SMO_TRY(run(Ax));
             {
