@@ -48,15 +48,18 @@ def main():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
         res[k] = {"instantiation": shapes[k], "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
-                  "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
-                  "lds_conflict_fraction": v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1),
-                  "wait_any_fraction": v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1)}
+                  "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
+        if "SQ_LDS_BANK_CONFLICT" in v and "SQ_LDS_IDX_ACTIVE" in v:          # only when the SQ passes were collected too
+            res[k]["lds_conflict_fraction"] = v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_LDS_IDX_ACTIVE"], 1)
+        if "SQ_WAIT_ANY" in v and "SQ_WAVE_CYCLES" in v:
+            res[k]["wait_any_fraction"] = v["SQ_WAIT_ANY"] / max(v["SQ_WAVE_CYCLES"], 1)
     json.dump({"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), averages per dispatch; hbm_bytes = "
                        "(2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-B "
                        "requests as 64 B; narrower accesses are uncalibrated)", "grid": sys.argv[3] if len(sys.argv) > 3 else "",
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items()):
-        print("%-34s %8.1f MB  lds-conflict %.2f  wait %.2f" % (k, v["hbm_bytes_per_launch"] / 1e6, v["lds_conflict_fraction"], v["wait_any_fraction"]))
+        print("%-34s %8.1f MB%s" % (k, v["hbm_bytes_per_launch"] / 1e6,
+                                    ("  lds-conflict %.2f" % v["lds_conflict_fraction"]) if "lds_conflict_fraction" in v else ""))
 
 
 if __name__ == "__main__":

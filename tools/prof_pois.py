@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from spheremanopt_amd import poiseuille as pz  # noqa: E402
 
 Nx = int(sys.argv[1]) if len(sys.argv) > 1 else 384

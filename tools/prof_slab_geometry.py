@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from spheremanopt_amd import kdyn_slab as ks  # noqa: E402
 
 
