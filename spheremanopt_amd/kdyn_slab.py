@@ -18,6 +18,8 @@ The time loop only *enqueues* work: the device phases (``smo_kdyn_op``) and the 
 The module-level callables keep the reference's replicated-vector semantics (FWD_Solve_KDyn.py:91-171: every rank holds the
 full vectors; gradients are all-gathered), so ``Optimise_On_Multi_Sphere`` runs unchanged, redundantly on every rank.
 """
+import os
+
 import numpy as np
 
 from . import _capi
@@ -114,18 +116,22 @@ class SlabKDyn:
         self.ops = ops
         self.elems = ops.elems                                  # complex128 per field group, all peers
         # exchange buffers as float64 pairs (RCCL has no complex type): 2 field groups x elems complex128
+        # SMO_SLAB_FORCE_EXCHANGE=1: keep the two sides apart and run the collective even on ONE rank (a self-copy through the process
+        # group) — lets a single-GPU box exercise the real RCCL call path (stream ordering, buffer views) of the multi-GPU loop
+        self.force_exchange = (self.world == 1 and os.environ.get("SMO_SLAB_FORCE_EXCHANGE", "0") == "1" and
+                               _dist().is_available() and _dist().is_initialized())
         self.buf_z = torch.zeros(4 * self.elems, dtype=torch.float64, device=self.dev)      # z-pass side (kx slab, all z)
-        self.buf_y = self.buf_z if self.world == 1 else torch.zeros_like(self.buf_z)        # y-pass side (all kx, z slab)
+        self.buf_y = self.buf_z if (self.world == 1 and not self.force_exchange) else torch.zeros_like(self.buf_z)   # y-pass side (all kx, z slab)
         ops.set_buffers(self.buf_z, self.buf_y)
         self.adj_groups = 1 if ops.keeps_grid_states else 2
-        backend = _dist().get_backend() if self.world > 1 else None
+        backend = _dist().get_backend() if (self.world > 1 or self.force_exchange) else None
         # collectives on device tensors need RCCL; with gloo (CPU tests, or several ranks sharing one GPU) stage through the host
         self.host_staged = (self.dev.type == "cuda" and backend == "gloo") if stage_through_host is None else stage_through_host
         self.have_forward = False
 
     # -- communication -----------------------------------------------------------------------------------------------
     def _exchange(self, src, dst, nfields):
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return
         n = 2 * nfields * self.elems                           # float64 words
         dist = _dist()

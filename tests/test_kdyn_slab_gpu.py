@@ -83,3 +83,42 @@ def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep)
     assert abs(float(r["J"]) - Jo) <= 1e-6 * abs(Jo)
     assert rel(r["gB"], goB) < 1e-6 and rel(r["gU"], goU) < 1e-6
     assert abs(float(r["ip"]) - o.inner(r["B"], goB)) <= 1e-6 * abs(o.inner(r["B"], goB))
+
+
+def _nccl_worker(rank, port, N, n, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMO_SLAB_FORCE_EXCHANGE="1")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from spheremanopt_amd import kdyn
+        from spheremanopt_amd.kdyn_slab import SlabKDyn
+        dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        args = [dom, 1., 1e-3, n, n, buf, "Final", "Discrete"]
+        J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+        g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        s = SlabKDyn(N, 1., 1e-3, n, "Final")
+        assert s.force_exchange and not s.host_staged and s.buf_y.data_ptr() != s.buf_z.data_ptr()
+        J1 = s.forward([s.local_slab(B), s.local_slab(U)])
+        g1 = s.adjoint("Discrete")
+        ip = s.inner(s.local_slab(B), g1[0])
+        np.savez(out, J0=J0, J1=J1, eB=np.abs(g1[0].cpu().numpy() - g0[0]).max(), eU=np.abs(g1[1].cpu().numpy() - g0[1]).max(),
+                 ip=ip, ip0=kdyn.Inner_Prod_3(B, g0[0], dom))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_call_path_on_one_rank(tmp_path):
+    """The real RCCL collectives of the multi-GPU time loop (all_to_all_single on the solver's own HIP stream, all_reduce of J and
+    <x,y>) on a one-rank process group, with the two exchange buffers kept apart: every transpose is a self-copy THROUGH the
+    collective, so the result must equal the monolithic single-GPU path bit for bit."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_nccl_worker, args=(_free_port(), 32, 4, out), nprocs=1, join=True)
+    r = np.load(out)
+    assert float(r["J1"]) == float(r["J0"])
+    assert float(r["eB"]) == 0.0 and float(r["eU"]) == 0.0
+    assert abs(float(r["ip"]) - float(r["ip0"])) < 1e-15
