@@ -34,8 +34,13 @@ struct Geom {
     int m;        // ky / kz modes (N-1)
     int kmax;     // (N-1)/2
     int G;        // grid points per axis (3N/2)
-    int Gzl;      // local z planes in grid space (G / world)
-    size_t blk;   // slab-exchange layout: elements between the blocks of consecutive peers (= field groups * 3 * al * m * Gzl)
+    int Gzl;      // z planes the y / x passes of one launch see: the rank's slab G / world, or one of its `chunks` equal parts
+    int Gzr;      // z planes per rank (G / world)
+    int W;        // number of slabs
+    int zg0;      // caller-layout grid vectors [3][G][G][Gzr]: first z plane of the chunk this launch works on
+    size_t blk;   // slab-exchange layout: elements of one (chunk, peer) block (= field groups * 3 * al * m * Gzl)
+    size_t cblk;  // elements between consecutive chunks (= W * 2 field groups * 3 * al * m * Gzl, whatever the number of groups in use,
+                  // so that a chunk's region with one group lies inside its region with two)
     int utile;    // x pass spectrum -> grid: 1 = write the tile-major layout of the internal U field (u_off), 0 = the flat X layout
     double Rm, dt;
 };
@@ -47,13 +52,21 @@ __device__ __forceinline__ int wrap_pos(int pos, const Geom& g) {      // positi
 }
 __device__ __forceinline__ double wavenumber(int idx, const Geom& g) { return (idx <= g.kmax) ? (double)idx : (double)(idx - g.m); }
 
-// Tz in the slab-exchange layout [peer][field group][3][al][m][Gzl] (the field-group offset is folded into the base pointer):
+// Tz in the slab-exchange layout [chunk (stride cblk)][peer][field group][3][al][m][Gzl] (the field-group offset is folded into the base pointer;
+// chunk-major so that every chunk is one contiguous all_to_all_single, which lets the host pipeline the exchange of one chunk with
+// the grid-side work on another):
 // z side: the peer index is the z block of `pos`; rt = ixl * m + iy is the local (kx, ky) row
 __device__ __forceinline__ size_t zs_off(int c, int rt, int pos, const Geom& g) {
-    const int p = pos / g.Gzl;
-    return (size_t)p * g.blk + ((size_t)c * (g.al * g.m) + rt) * g.Gzl + (pos - p * g.Gzl);
+    const int p = pos / g.Gzr, zl = pos - p * g.Gzr;
+    const int k = zl / g.Gzl, zc = zl - k * g.Gzl;
+    return (size_t)k * g.cblk + (size_t)p * g.blk + ((size_t)c * (g.al * g.m) + rt) * g.Gzl + zc;
 }
-// y side: the peer index is the kx block; offset of the (c, kx, iy = 0) row, z local
+// caller-layout grid vector [3][G][G][Gzr]: offset of (c, x) at flat (y, z) index i of the chunk
+__device__ __forceinline__ size_t grid_off(int c, int x, size_t i, const Geom& g) {
+    const size_t y = i / g.Gzl;
+    return (((size_t)c * g.G + x) * g.G + y) * g.Gzr + g.zg0 + (i - y * g.Gzl);
+}
+// y side (inside one chunk): the peer index is the kx block; offset of the (c, kx, iy = 0) row, z local
 __device__ __forceinline__ size_t ys_row0(int c, int kx, const Geom& g) {
     const int q = kx / g.al;
     return (size_t)q * g.blk + ((size_t)c * g.al + (kx - q * g.al)) * ((size_t)g.m * g.Gzl);
@@ -294,7 +307,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     auto ld_grid = [&](int b, int pos) -> cplx {
         const int p = b % HP, c = b / HP;
         if (!line_ok(p)) return mk(0, 0);
-        const double* q = gridU + ((size_t)c * g.G + pos) * plane + i0 + 2 * p;
+        const double* q = gridU + grid_off(c, pos, i0 + 2 * p, g);
         return mk(q[0], q[1]);
     };
     auto st_buf = [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; };
@@ -303,7 +316,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         fft_inplace<L, true, NB, NT, true, false, false>(buf, LD, tw, tid, ld_spec, [&](int b, int pos, cplx v) {
             const int p = b % HP, c = b / HP;
             if (line_ok(p)) {
-                double* q = gridOut + (g.utile ? u_off(c, pos, i0 + 2 * p, g) : ((size_t)c * g.G + pos) * plane + i0 + 2 * p);
+                double* q = gridOut + (g.utile ? u_off(c, pos, i0 + 2 * p, g) : grid_off(c, pos, i0 + 2 * p, g));
                 q[0] = v.re; q[1] = v.im;
             }
         });
@@ -446,8 +459,12 @@ public:
     explicit KDyn(const smo_config& c) { cfg = c; }
     Geom g{};
     size_t nmode = 0, tzb = 0, n_ex = 0, n_grid = 0, fld = 0;
-    // tzb = 3*al*m*Gzl: one field group of Tz inside a peer block of the exchange layout;  n_ex = 2*W*tzb: a whole exchange buffer
-    // fld = 3*a*G*Gzl:  one field group of Ty (all kx, local z planes) = what the x pass reads
+    // tzb = 3*al*m*Gzr: one field group of Tz, per peer;  n_ex = 2*W*tzb: a whole exchange buffer (two field groups, all peers)
+    // fld = 3*a*G*Gzr:  one field group of Ty (all kx, local z planes) = what the x pass reads
+    // The rank's z slab can be cut into K equal chunks (SMO_KD_SET_CHUNKS): the grid-side phases then work chunk by chunk and every
+    // chunk of an exchange buffer is contiguous, so the host layer can overlap the exchange of one chunk with the work on another.
+    int K = 1;
+    size_t tzc = 0, fldc = 0, ngc = 0;       // per chunk: tzb / K, fld / K, n_grid / K
     cplx *d_stack = nullptr, *d_ty = nullptr, *d_G = nullptr, *d_nu = nullptr, *d_tw = nullptr;
     cplx *zs = nullptr, *ys = nullptr;      // Tz exchange buffers: z-pass side / y-pass side (one and the same when world == 1)
     double *d_U = nullptr, *d_part = nullptr;
@@ -468,10 +485,20 @@ public:
         if (idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
         const int w = idx / ck, last = std::min(cfg.n_iters, w * ck + ck - 1);
         scratch_window = w;
-        for (int n = w * ck; n < last; ++n) { SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B()); SMO_TRY(fwd_C(n)); }
+        for (int n = w * ck; n < last; ++n) { SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(-1, 0)); SMO_TRY(fwd_C(n)); }
         return SMO_OK;
     }
-    Geom geom(int nfields) const { Geom q = g; q.blk = (size_t)nfields * tzb; return q; }
+    Geom geom(int nfields, int k = 0) const { Geom q = g; q.blk = (size_t)nfields * tzc; q.cblk = (size_t)cfg.world * 2 * tzc; q.zg0 = k * g.Gzl; return q; }
+    int set_chunks(int k) {
+        const int Gzc = k > 0 ? g.Gzr / k : 0;
+        if (k < 1 || g.Gzr % k != 0 || (Gzc & 1) || ((size_t)g.G * Gzc) % 4 != 0) {
+            set_error("KDYN: %d chunks do not divide the %d local z planes into even parts with G*Gz %% 4 == 0", k, g.Gzr);
+            return SMO_ERR_ARG;
+        }
+        K = k; g.Gzl = Gzc; tzc = tzb / K; fldc = fld / K; ngc = n_grid / K;
+        have_forward = false;
+        return SMO_OK;
+    }
 
     int init() override {
         const int N = cfg.npts, W = cfg.world;
@@ -484,7 +511,7 @@ public:
             set_error("KDYN: %d slabs do not divide a=%d kx modes and G=%d grid planes", W, N / 2, 3 * N / 2);
             return SMO_ERR_UNSUPPORTED;
         }
-        g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gzl = g.G / W;
+        g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gzl = g.Gzr = g.G / W; g.W = W; g.zg0 = 0;
         g.Rm = cfg.param; g.dt = cfg.dt;
         nmode = (size_t)g.al * g.m * g.m;
         tzb = (size_t)3 * g.al * g.m * g.Gzl;
@@ -492,6 +519,7 @@ public:
         fld = (size_t)3 * g.a * g.G * g.Gzl;
         n_grid = (size_t)3 * g.G * g.G * g.Gzl;          // local slab of a grid vector: [3][G][G][Gzl]
         g.blk = tzb;
+        tzc = tzb; fldc = fld; ngc = n_grid;
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
@@ -577,7 +605,7 @@ public:
     // coefficients -> field group `f` (of `nf`) of the z-side exchange buffer
     int z_inverse(int mode, const cplx* in, int f, int nf) {
         const Geom g = geom(nf);
-        cplx* out = zs + (size_t)f * tzb;
+        cplx* out = zs + (size_t)f * tzc;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -589,10 +617,10 @@ public:
             return SMO_OK;
         });
     }
-    // y pass between field group `f` (of `nf`) of the y-side exchange buffer and one field group of Ty at `ty`
-    int y_pass(bool inv, int f, int nf, cplx* ty) {
-        const Geom q = geom(nf);
-        cplx* ex = ys + (size_t)f * tzb;
+    // y pass between field group `f` (of `nf`) of chunk `k` of the y-side exchange buffer and (that chunk of) one field group of Ty at `ty`
+    int y_pass(bool inv, int f, int nf, cplx* ty, int k = 0) {
+        const Geom q = geom(nf, k);
+        cplx* ex = ys + (size_t)k * q.cblk + (size_t)f * tzc;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -609,18 +637,24 @@ public:
             return SMO_OK;
         });
     }
-    // inA / inB: read the spectra of field group A / B from elsewhere (e.g. the Ty stack) instead of the x-side buffer
-    int x_pass(int mode, const double* grid_in, double* grid_out, const cplx* inA = nullptr, const cplx* inB = nullptr) {
+    // chunk `k` of the grid stage.  vec_in / vec_out: caller-layout grid vectors (X_FROM_GRID / X_TO_GRID); vec_out == nullptr with
+    // X_TO_GRID writes the internal (tile-major) U field.  inA / inB: read the spectra of field group A / B from elsewhere (the Ty stack).
+    int x_pass(int mode, int k, const double* vec_in, double* vec_out, const cplx* inA = nullptr, const cplx* inB = nullptr) {
         const size_t plane = (size_t)g.G * g.Gzl;
-        Geom q = g;
-        q.utile = (mode == X_TO_GRID && grid_out == d_U) ? 1 : 0;
-        const XSpec sp{inA ? inA : d_ty, inB ? inB : d_ty + fld, d_ty, d_ty + fld};
+        Geom q = geom(1, k);
+        const bool to_U = (mode == X_TO_GRID && vec_out == nullptr);
+        q.utile = to_U ? 1 : 0;
+        double* Uk = d_U + (size_t)k * ngc;
+        const double* grid_in = (mode == X_FROM_GRID) ? vec_in : Uk;
+        double* grid_out = to_U ? Uk : vec_out;
+        cplx *tA = d_ty + (size_t)k * fldc, *tB = d_ty + fld + (size_t)k * fldc;
+        const XSpec sp{inA ? inA : tA, inB ? inB : tB, tA, tB};
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
-            const int k = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
-            ScopedTimer t(timing, k, stream);
+            const int kc = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
+            ScopedTimer t(timing, kc, stream);
             switch (mode) {
                 case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
@@ -633,7 +667,7 @@ public:
     // z-side exchange buffer (field groups 0 [and 1]) -> coefficients / time-step update
     int z_forward(int mode, cplx* out0, cplx* out1, const cplx* state0, const cplx* snp) {
         const Geom g = geom(mode == ZF_ADJ_UPDATE ? 2 : 1);
-        const cplx *inA = zs, *inB = zs + tzb;
+        const cplx *inA = zs, *inB = zs + tzc;
         const double scale = 1.0 / ((double)g.G * g.G * g.G);
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
         return with_L([&](auto l) {
@@ -658,14 +692,15 @@ public:
     // step then reads B_f from there: no z / y pass of the snapshot (2 of its 8 kernels) and, with slabs, one field group less to
     // exchange.
     cplx* d_tystack = nullptr;
-    cplx* tyslot(int n) { return d_tystack + (size_t)n * fld; }
+    cplx* tyslot(int n, int k = 0) { return d_tystack + (size_t)n * fld + (size_t)k * fldc; }
+    cplx* tyw(int f, int k) { return d_ty + (size_t)f * fld + (size_t)k * fldc; }       // work copy of Ty: field group f, chunk k
     bool have_ty(int n) const { return d_tystack != nullptr && n >= 0 && n < cfg.n_iters; }
     int fwd_A(int n) { return z_inverse(ZI_PLAIN, snap(n), 0, 1); }
-    int fwd_B(int n = -1) {
-        cplx* ty = have_ty(n) ? tyslot(n) : d_ty;
-        SMO_TRY(y_pass(true, 0, 1, ty));
-        SMO_TRY(x_pass(X_FUSED_FWD, d_U, nullptr, ty));
-        return y_pass(false, 0, 1, d_ty);
+    int fwd_B(int n, int k) {
+        cplx* ty = have_ty(n) ? tyslot(n, k) : tyw(0, k);
+        SMO_TRY(y_pass(true, 0, 1, ty, k));
+        SMO_TRY(x_pass(X_FUSED_FWD, k, nullptr, nullptr, ty));
+        return y_pass(false, 0, 1, tyw(0, k), k);
     }
     int fwd_C(int n) { return z_forward(ZF_FWD_UPDATE, snap(n + 1), nullptr, snap(n), nullptr); }
     int adj_init(int adjoint_type) {
@@ -681,21 +716,21 @@ public:
         SMO_TRY(z_inverse(ZI_CURL, d_G, 0, nf));
         return nf == 2 ? z_inverse(ZI_PLAIN, snap(idx), 1, 2) : SMO_OK;
     }
-    int adj_B(int idx) {
+    int adj_B(int idx, int k) {
         const int nf = adj_groups(idx);
-        SMO_TRY(y_pass(true, 0, nf, d_ty));
-        if (nf == 2) SMO_TRY(y_pass(true, 1, 2, d_ty + fld));
-        SMO_TRY(x_pass(X_FUSED_ADJ, d_U, nullptr, nullptr, nf == 1 ? tyslot(idx) : nullptr));
-        SMO_TRY(y_pass(false, 0, 2, d_ty));
-        return y_pass(false, 1, 2, d_ty + fld);
+        SMO_TRY(y_pass(true, 0, nf, tyw(0, k), k));
+        if (nf == 2) SMO_TRY(y_pass(true, 1, 2, tyw(1, k), k));
+        SMO_TRY(x_pass(X_FUSED_ADJ, k, nullptr, nullptr, nullptr, nf == 1 ? tyslot(idx, k) : nullptr));
+        SMO_TRY(y_pass(false, 0, 2, tyw(0, k), k));
+        return y_pass(false, 1, 2, tyw(1, k), k);
     }
     int adj_C(int idx) { return z_forward(ZF_ADJ_UPDATE, d_G, d_nu, d_G, snap(idx)); }
     // grid vector (local slab of the flat X layout) -> truncated coefficients, in two phases around the exchange
-    int g2c_A(const double* X) { SMO_TRY(x_pass(X_FROM_GRID, X, nullptr)); return y_pass(false, 0, 1, d_ty); }
+    int g2c_A(const double* X, int k) { SMO_TRY(x_pass(X_FROM_GRID, k, X, nullptr)); return y_pass(false, 0, 1, tyw(0, k), k); }
     int g2c_C(cplx* out) { return z_forward(ZF_PLAIN, out, nullptr, nullptr, nullptr); }
     // coefficients -> grid; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
     int c2g_A(const cplx* C, bool scaled) { return z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, 0, 1); }
-    int c2g_B(double* X) { SMO_TRY(y_pass(true, 0, 1, d_ty)); return x_pass(X_TO_GRID, nullptr, X); }
+    int c2g_B(double* X, int k) { SMO_TRY(y_pass(true, 0, 1, tyw(0, k), k)); return x_pass(X_TO_GRID, k, nullptr, X); }   // X == nullptr: the U field
 
     int reduce_partials(double* out) {
         SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -715,6 +750,7 @@ public:
 
     // ---- the three callbacks (single GPU: phases back to back, no exchange) -----------------------------------------
     int single_only(const char* who) {
+        if (K != 1) { set_error("%s: the z slab is cut into %d chunks (phase-level use only)", who, K); return SMO_ERR_STATE; }
         if (cfg.world != 1) { set_error("%s: with %d slabs the host layer drives the phases (smo_kdyn_op)", who, cfg.world); return SMO_ERR_STATE; }
         return SMO_OK;
     }
@@ -723,9 +759,9 @@ public:
         have_forward = false;
         const int N = cfg.n_iters;
         // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver)
-        SMO_TRY(g2c_A(X[1])); SMO_TRY(g2c_C(d_G));
-        SMO_TRY(c2g_A(d_G, false)); SMO_TRY(c2g_B(d_U));
-        SMO_TRY(g2c_A(X[0])); SMO_TRY(g2c_C(snap(0)));
+        SMO_TRY(g2c_A(X[1], 0)); SMO_TRY(g2c_C(d_G));
+        SMO_TRY(c2g_A(d_G, false)); SMO_TRY(c2g_B(nullptr, 0));
+        SMO_TRY(g2c_A(X[0], 0)); SMO_TRY(g2c_C(snap(0)));
         double Jacc = 0.0, E = 0.0;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         for (int n = 0; n < N; ++n) {
@@ -733,7 +769,7 @@ public:
                 ScopedTimer t(timing, k_misc, stream);
                 hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(n), d_part + (size_t)n * NPART, g);
             }
-            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(n)); SMO_TRY(fwd_C(n));
+            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(n, 0)); SMO_TRY(fwd_C(n));
         }
         scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
         if (integ) {
@@ -766,9 +802,9 @@ public:
         SMO_TRY(ensure(N));
         SMO_TRY(adj_init(adjoint_type));
         int idx = cont ? N : N - 1;
-        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B(idx)); SMO_TRY(adj_C(idx)); }
-        SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0]));
-        SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1]));
+        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B(idx, 0)); SMO_TRY(adj_C(idx)); }
+        SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0], 0));
+        SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1], 0));
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
         return SMO_OK;
@@ -797,7 +833,7 @@ public:
 
     // ---- phase-level entry for the slab-decomposed driver (smo_kdyn_op) -------------------------------------------------
     int kdyn_op(int op, int i0, int i1, void* p0, void* p1, double* out) override {
-        (void)i1;
+        if (op == SMO_KD_SET_CHUNKS) return set_chunks(i0);
         if (op == SMO_KD_SET_BUFFERS) {
             if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
             zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1);
@@ -806,22 +842,23 @@ public:
         if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(tzb * cfg.world); return SMO_OK; }
         SMO_TRY(need_buffers());
         const int N = cfg.n_iters;
+        auto chunk_ok = [&](int k) { if (k < 0 || k >= K) { set_error("smo_kdyn_op(%d): chunk %d out of range (%d chunks)", op, k, K); return false; } return true; };
         auto step_ok = [&](int n, int hi) { if (n < 0 || n > hi) { set_error("smo_kdyn_op(%d): index %d out of range", op, n); return false; } return true; };
         int rc = SMO_OK;
         switch (op) {
-            case SMO_KD_G2C_A: if (!p0) return SMO_ERR_ARG; rc = g2c_A(static_cast<const double*>(p0)); break;
+            case SMO_KD_G2C_A: if (!p0 || !chunk_ok(i1)) return SMO_ERR_ARG; rc = g2c_A(static_cast<const double*>(p0), i1); break;
             case SMO_KD_G2C_C: rc = g2c_C(i0 == 0 ? snap(0) : d_G); if (i0 == 0) have_forward = false; break;
             case SMO_KD_C2G_A: rc = c2g_A(i0 == 2 ? d_nu : d_G, i0 == 0); break;
-            case SMO_KD_C2G_B: rc = c2g_B(p0 ? static_cast<double*>(p0) : d_U); break;
+            case SMO_KD_C2G_B: if (!chunk_ok(i1)) return SMO_ERR_ARG; rc = c2g_B(static_cast<double*>(p0), i1); break;
             case SMO_KD_FWD_A: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_A(i0); break;
-            case SMO_KD_FWD_B: rc = fwd_B(i0); break;
+            case SMO_KD_FWD_B: if (!chunk_ok(i1)) return SMO_ERR_ARG; rc = fwd_B(i0, i1); break;
             case SMO_KD_FWD_C: if (!step_ok(i0, N - 1)) return SMO_ERR_ARG; rc = fwd_C(i0); if (i0 == N - 1) have_forward = true; break;
             case SMO_KD_ENERGY: if (!step_ok(i0, N) || !out) return SMO_ERR_ARG; return energy(snap(i0), out);
             case SMO_KD_ADJ_INIT:
                 if (!have_forward) { set_error("smo_kdyn_op: adjoint before forward"); return SMO_ERR_STATE; }
                 rc = adj_init(i0); break;
             case SMO_KD_ADJ_A: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_A(i0); break;
-            case SMO_KD_ADJ_B: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_B(i0); break;
+            case SMO_KD_ADJ_B: if (!step_ok(i0, N) || !chunk_ok(i1)) return SMO_ERR_ARG; rc = adj_B(i0, i1); break;
             case SMO_KD_ADJ_C: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_C(i0); break;
             case SMO_KD_SYNC: SMO_HIP(hipStreamSynchronize(stream)); break;
             default: set_error("smo_kdyn_op: unknown op %d", op); return SMO_ERR_ARG;

@@ -26,7 +26,7 @@ from . import _capi
 
 # op codes of include/smo.h
 (SET_BUFFERS, EXCHANGE_ELEMS, G2C_A, G2C_C, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, ENERGY, ADJ_INIT, ADJ_A, ADJ_B, ADJ_C,
- SYNC) = range(15)
+ SYNC, SET_CHUNKS) = range(16)
 
 
 def _dist():
@@ -60,10 +60,13 @@ class HipOps:
         self.elems = int(out.value)
         self.vec_len = self.ctx.vec_len
 
-    def op(self, code, i0=0, p0=None, p1=None, out=None):
+    def op(self, code, i0=0, p0=None, p1=None, out=None, i1=0):
         C = self._C
         ref = C.byref(out) if out is not None else None
-        _capi._check(self.lib.smo_kdyn_op(self.ctx._h, code, int(i0), 0, C.c_void_p(p0), C.c_void_p(p1), ref))
+        _capi._check(self.lib.smo_kdyn_op(self.ctx._h, code, int(i0), int(i1), C.c_void_p(p0), C.c_void_p(p1), ref))
+
+    def set_chunks(self, K):
+        self.op(SET_CHUNKS, K)
 
     def set_buffers(self, zs, ys):
         self.op(SET_BUFFERS, p0=zs.data_ptr(), p1=ys.data_ptr())
@@ -81,8 +84,8 @@ class HipOps:
     def dot(self, x, y):
         return self.ctx.inner_dev(x, y)
 
-    def phase(self, code, i0=0, vec=None):
-        self.op(code, i0, p0=(vec.data_ptr() if vec is not None else None))
+    def phase(self, code, i0=0, vec=None, k=0):
+        self.op(code, i0, p0=(vec.data_ptr() if vec is not None else None), i1=k)
 
     def sync(self):
         self.op(SYNC)
@@ -94,7 +97,7 @@ class HipOps:
 class SlabKDyn:
     """One rank's share of the forward / adjoint solve.  `ops` is the phase backend (HipOps unless a test injects its own)."""
 
-    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function="Final", device=None, ops=None, stage_through_host=None):
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function="Final", device=None, ops=None, stage_through_host=None, chunks=None):
         import torch
         self.torch = torch
         self.rank, self.world = rank_world()
@@ -124,25 +127,63 @@ class SlabKDyn:
         self.buf_y = self.buf_z if (self.world == 1 and not self.force_exchange) else torch.zeros_like(self.buf_z)   # y-pass side (all kx, z slab)
         ops.set_buffers(self.buf_z, self.buf_y)
         self.adj_groups = 1 if ops.keeps_grid_states else 2
+        # pipelining: the local z slab is cut into K chunks; the all-to-all of chunk k overlaps the grid-side kernels of the other chunks
+        # (the collectives run on the process group's own stream, the kernels on the solver's).  Default: 24 or more planes per chunk.
+        if chunks is None:
+            chunks = int(os.environ.get("SMO_SLAB_CHUNKS", "0")) or (max(1, min(4, self.Gzl // 24)) if self.world > 1 else 1)
+        while chunks > 1 and (self.Gzl % chunks or (self.Gzl // chunks) % 2 or (self.G * (self.Gzl // chunks)) % 4):
+            chunks -= 1
+        self.K = chunks
+        if self.K > 1:
+            ops.set_chunks(self.K)
         backend = _dist().get_backend() if (self.world > 1 or self.force_exchange) else None
         # collectives on device tensors need RCCL; with gloo (CPU tests, or several ranks sharing one GPU) stage through the host
         self.host_staged = (self.dev.type == "cuda" and backend == "gloo") if stage_through_host is None else stage_through_host
         self.have_forward = False
 
     # -- communication -----------------------------------------------------------------------------------------------
-    def _exchange(self, src, dst, nfields):
+    def _exchange(self, src, dst, nfields, k=0, wait=True):
+        """All-to-all of chunk k (nfields field groups) from `src` to `dst`.  With RCCL the collective is enqueued on the process
+        group's stream behind everything already on the solver's stream; `wait=False` returns the work handle so that kernels
+        enqueued next (on other chunks) overlap it — call `_wait(handle)` before the first kernel that reads `dst`."""
         if self.world == 1 and not self.force_exchange:
-            return
-        n = 2 * nfields * self.elems                           # float64 words
+            return None
+        n = 2 * nfields * self.elems // self.K                  # float64 words of this chunk
+        c0 = k * (4 * self.elems // self.K)                     # chunks are spaced for two field groups whatever `nfields` is
+        s_, d_ = src[c0:c0 + n], dst[c0:c0 + n]
         dist = _dist()
         if self.host_staged:
             self.ops.sync()
-            s = src[:n].cpu()
-            d = self.torch.empty_like(s)
-            dist.all_to_all_single(d, s)
-            dst[:n].copy_(d)
-        else:
-            dist.all_to_all_single(dst[:n], src[:n])
+            h = s_.cpu()
+            r = self.torch.empty_like(h)
+            dist.all_to_all_single(r, h)
+            d_.copy_(r)
+            return None
+        if wait:
+            dist.all_to_all_single(d_, s_)
+            return None
+        return dist.all_to_all_single(d_, s_, async_op=True)
+
+    @staticmethod
+    def _wait(work):
+        if work is not None:
+            work.wait()                                         # stream-level: the solver's stream waits, the host does not
+
+    def _grid_stage(self, code, i0, to_y, to_z, nf_in, nf_out):
+        """One transpose -> grid work -> transpose back, chunk-pipelined: z-side -> y-side, phase `code` per chunk, y-side -> z-side."""
+        if self.K == 1:
+            self._exchange(to_y[0], to_y[1], nf_in)
+            self.ops.phase(code, i0)
+            self._exchange(to_z[0], to_z[1], nf_out)
+            return
+        inbound = [self._exchange(to_y[0], to_y[1], nf_in, k, wait=False) for k in range(self.K)]
+        outbound = []
+        for k in range(self.K):
+            self._wait(inbound[k])
+            self.ops.phase(code, i0, k=k)
+            outbound.append(self._exchange(to_z[0], to_z[1], nf_out, k, wait=False))
+        for w in outbound:
+            self._wait(w)
 
     def _allreduce(self, value):
         if self.world == 1:
@@ -154,14 +195,16 @@ class SlabKDyn:
 
     # -- transforms of whole vectors ------------------------------------------------------------------------------------
     def _grid_to_coeff(self, vec, target):
-        self.ops.phase(G2C_A, vec=vec)
-        self._exchange(self.buf_y, self.buf_z, 1)
+        for k in range(self.K):
+            self.ops.phase(G2C_A, vec=vec, k=k)
+            self._exchange(self.buf_y, self.buf_z, 1, k)
         self.ops.phase(G2C_C, target)
 
     def _coeff_to_grid(self, source, vec):
         self.ops.phase(C2G_A, source)
-        self._exchange(self.buf_z, self.buf_y, 1)
-        self.ops.phase(C2G_B, vec=vec)
+        for k in range(self.K):
+            self._exchange(self.buf_z, self.buf_y, 1, k)
+            self.ops.phase(C2G_B, vec=vec, k=k)
 
     # -- the three callbacks on local slabs --------------------------------------------------------------------------------
     def _on_stream(self):
@@ -202,9 +245,8 @@ class SlabKDyn:
             if integ:
                 J += self.dt * self.ops.energy(n)
             self.ops.phase(FWD_A, n)                       # z pass (inverse)
-            self._exchange(self.buf_z, self.buf_y, 1)
-            self.ops.phase(FWD_B, n)                       # y, x passes, U x B on the grid, x, y passes back
-            self._exchange(self.buf_y, self.buf_z, 1)
+            # transpose, then y, x passes, U x B on the grid, x, y passes back, transpose back (chunk-pipelined)
+            self._grid_stage(FWD_B, n, (self.buf_z, self.buf_y), (self.buf_y, self.buf_z), 1, 1)
             self.ops.phase(FWD_C, n)                       # z pass (forward) + curl, projection, CNAB1 update
         E = self.ops.energy(self.n_iters)
         J = J + self.dt * E if integ else E
@@ -219,9 +261,8 @@ class SlabKDyn:
         idx = self.n_iters if cont else self.n_iters - 1
         for _ in range(self.n_iters):
             self.ops.phase(ADJ_A, idx)
-            self._exchange(self.buf_z, self.buf_y, self.adj_groups if idx < self.n_iters else 2)
-            self.ops.phase(ADJ_B, idx)
-            self._exchange(self.buf_y, self.buf_z, 2)
+            self._grid_stage(ADJ_B, idx, (self.buf_z, self.buf_y), (self.buf_y, self.buf_z),
+                             self.adj_groups if idx < self.n_iters else 2, 2)
             self.ops.phase(ADJ_C, idx)
             idx -= 1
         if out is None:

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: a NumPy phase backend for spheremanopt_amd.kdyn_slab.SlabKDyn, used to cover the N>1 driver logic
 (exchange layout, phase order, reductions) with world_size-2 gloo runs on the CPU.  It restates, per slab, what the HIP
-phases of csrc/kdyn.hip do, reading/writing the exchange buffers in exactly their [peer][field][3][a/W][m][G/W] layout,
+phases of csrc/kdyn.hip do, reading/writing the exchange buffers in exactly their [chunk][peer][field][3][a/W][m][G/W/K] layout,
 and borrows the per-mode algebra from the oracle."""
 import numpy as np
 from scipy import fft as sfft
@@ -27,28 +27,43 @@ class NumpyOps:
         self.n_iters, self.dt, self.cost = N_ITERS, dt, Cost_function
         self.stack = np.zeros((N_ITERS + 1, 3, self.al, self.m, self.m), dtype=complex)
         self.keeps_grid_states = keeps_grid_states                        # the device's "Ty stack": B_n on the grid side, per step
+        self.K = 1                                                        # chunks of the local z slab (set_chunks)
         self.Bgrid = {}
         self.Gh = self.nu = self.scratch = None
         self.U = None
 
-    # -- buffers: [peer][field group][3][al][m][Gzl] on both sides -----------------------------------------------------------
+    # -- buffers: [chunk (spaced for 2 groups)][peer][field group][3][al][m][Gzl / K] on both sides ------------------------------------------------------
     def set_buffers(self, zs, ys):
         self.bz, self.by = zs.numpy().view(np.complex128), ys.numpy().view(np.complex128)
 
-    def _view(self, buf, nf):
-        return buf[:nf * self.elems].reshape(self.W, nf, 3, self.al, self.m, self.Gzl)
+    def set_chunks(self, K):
+        assert self.Gzl % K == 0
+        self.K = K
 
-    def _put_z(self, Tz, f, nf):          # Tz: (3, al, m, G): my kx, all z -> peer = z block
-        self._view(self.bz, nf)[:, f] = Tz.reshape(3, self.al, self.m, self.W, self.Gzl).transpose(3, 0, 1, 2, 4)
+    def _chunk(self, buf, nf, k):         # chunk k: [peer][nf][3][al][m][Gzc]; chunks are spaced for two field groups whatever nf is
+        n, stride = nf * self.elems // self.K, 2 * self.elems // self.K
+        return buf[k * stride:k * stride + n].reshape(self.W, nf, 3, self.al, self.m, self.Gzl // self.K)
+
+    def _put_z(self, Tz, f, nf):          # Tz: (3, al, m, G): my kx, all z -> peer = z block, chunk = part of that block
+        T = Tz.reshape(3, self.al, self.m, self.W, self.K, self.Gzl // self.K)
+        for k in range(self.K):
+            self._chunk(self.bz, nf, k)[:, f] = T[:, :, :, :, k].transpose(3, 0, 1, 2, 4)
 
     def _get_z(self, f, nf):
-        return self._view(self.bz, nf)[:, f].transpose(1, 2, 3, 0, 4).reshape(3, self.al, self.m, self.G)
+        T = np.empty((3, self.al, self.m, self.W, self.K, self.Gzl // self.K), dtype=complex)
+        for k in range(self.K):
+            T[:, :, :, :, k] = self._chunk(self.bz, nf, k)[:, f].transpose(1, 2, 3, 0, 4)
+        return T.reshape(3, self.al, self.m, self.G)
 
-    def _get_y(self, f, nf):              # -> (3, a, m, Gzl): all kx (peer = kx block), my z
-        return self._view(self.by, nf)[:, f].transpose(1, 0, 2, 3, 4).reshape(3, self.a, self.m, self.Gzl)
+    def _get_y(self, f, nf, k):           # -> (3, a, m, Gzc): all kx (peer = kx block), chunk k of my z
+        return self._chunk(self.by, nf, k)[:, f].transpose(1, 0, 2, 3, 4).reshape(3, self.a, self.m, self.Gzl // self.K)
 
-    def _put_y(self, T, f, nf):
-        self._view(self.by, nf)[:, f] = T.reshape(3, self.W, self.al, self.m, self.Gzl).transpose(1, 0, 2, 3, 4)
+    def _put_y(self, T, f, nf, k):
+        self._chunk(self.by, nf, k)[:, f] = T.reshape(3, self.W, self.al, self.m, self.Gzl // self.K).transpose(1, 0, 2, 3, 4)
+
+    def _zs(self, k):                     # z planes of chunk k inside the local slab
+        c = self.Gzl // self.K
+        return slice(k * c, (k + 1) * c)
 
     # -- 1-D passes on slabs -----------------------------------------------------------------------------------------------
     def _z_inverse(self, C):              # (3, al, m, m) -> (3, al, m, G)
@@ -59,11 +74,11 @@ class NumpyOps:
     def _z_forward(self, Tz):
         return sfft.fft(Tz, axis=3)[..., self.o.sel] / float(self.G) ** 3
 
-    def _yx_to_grid(self, T):             # (3, a, m, Gzl) -> real (3, G, G, Gzl)
-        o, G = self.o, self.G
-        q = np.zeros((3, self.a, G, self.Gzl), dtype=complex); q[:, :, o.sel] = T
+    def _yx_to_grid(self, T):             # (3, a, m, nz) -> real (3, G, G, nz)
+        o, G, nz = self.o, self.G, T.shape[-1]
+        q = np.zeros((3, self.a, G, nz), dtype=complex); q[:, :, o.sel] = T
         q = sfft.ifft(q, axis=2) * G
-        r = np.zeros((3, G // 2 + 1, G, self.Gzl), dtype=complex); r[:, :self.a] = q
+        r = np.zeros((3, G // 2 + 1, G, nz), dtype=complex); r[:, :self.a] = q
         return sfft.irfft(r, n=G, axis=1) * G
 
     def _xy_from_grid(self, g):
@@ -71,11 +86,12 @@ class NumpyOps:
         return sfft.fft(c, axis=2)[:, :, self.o.sel]
 
     # -- phases ------------------------------------------------------------------------------------------------------------
-    def phase(self, code, i0=0, vec=None):
+    def phase(self, code, i0=0, vec=None, k=0):
         o = self.o
+        zs = self._zs(k)
         grid = (lambda t: t.numpy().reshape(3, self.G, self.G, self.Gzl)) if vec is not None else None
         if code == G2C_A:
-            self._put_y(self._xy_from_grid(grid(vec)), 0, 1)
+            self._put_y(self._xy_from_grid(grid(vec)[..., zs]), 0, 1, k)
         elif code == G2C_C:
             c = self._z_forward(self._get_z(0, 1))
             if i0 == 0:
@@ -88,18 +104,20 @@ class NumpyOps:
                    2: lambda: self.nu}[i0]()
             self._put_z(self._z_inverse(src), 0, 1)
         elif code == C2G_B:
-            g = self._yx_to_grid(self._get_y(0, 1))
+            g = self._yx_to_grid(self._get_y(0, 1, k))
             if vec is None:
-                self.U = g
+                if self.U is None or self.U.shape[-1] != self.Gzl:
+                    self.U = np.zeros((3, self.G, self.G, self.Gzl))
+                self.U[..., zs] = g
             else:
-                grid(vec)[...] = g
+                grid(vec)[..., zs] = g
         elif code == FWD_A:
             self._put_z(self._z_inverse(self.stack[i0]), 0, 1)
         elif code == FWD_B:
-            Bg = self._yx_to_grid(self._get_y(0, 1))
+            Bg = self._yx_to_grid(self._get_y(0, 1, k))
             if self.keeps_grid_states:
-                self.Bgrid[i0] = Bg
-            self._put_y(self._xy_from_grid(o.cross(self.U, Bg)), 0, 1)
+                self.Bgrid[(i0, k)] = Bg
+            self._put_y(self._xy_from_grid(o.cross(self.U[..., zs], Bg)), 0, 1, k)
         elif code == FWD_C:
             E = self._z_forward(self._get_z(0, 1))
             self.stack[i0 + 1] = o.cnab_update(self.stack[i0], o.curl(E))
@@ -120,10 +138,11 @@ class NumpyOps:
                 if not kept:
                     self._put_z(self._z_inverse(self.stack[i0]), 1, 2)
             else:
-                om = self._yx_to_grid(self._get_y(0, nf))
-                Bf = self.Bgrid[i0] if kept else self._yx_to_grid(self._get_y(1, 2))
-                self._put_y(self._xy_from_grid(o.cross(om, self.U)), 0, 2)
-                self._put_y(self._xy_from_grid(o.cross(om, Bf)), 1, 2)
+                om = self._yx_to_grid(self._get_y(0, nf, k))
+                Bf = self.Bgrid[(i0, k)] if kept else self._yx_to_grid(self._get_y(1, 2, k))
+                F1, F2 = self._xy_from_grid(o.cross(om, self.U[..., zs])), self._xy_from_grid(o.cross(om, Bf))
+                self._put_y(F1, 0, 2, k)
+                self._put_y(F2, 1, 2, k)
         elif code == ADJ_C:
             F1 = self._z_forward(self._get_z(0, 2)); F2 = -self._z_forward(self._get_z(1, 2))
             if self.cost == "Integrated":

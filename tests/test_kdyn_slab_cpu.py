@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, n, cost, adj, keep, out):
+def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
@@ -30,7 +30,8 @@ def _worker(rank, world, port, N, n, cost, adj, keep, out):
         G = 3 * N // 2
         B = synthetic_field(G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * G ** 3)
         U = synthetic_field(G, 2)
-        s = SlabKDyn(N, 1.3, 1e-2, n, cost, ops=NumpyOps(N, 1.3, 1e-2, n, cost, rank, world, keeps_grid_states=keep))
+        s = SlabKDyn(N, 1.3, 1e-2, n, cost, ops=NumpyOps(N, 1.3, 1e-2, n, cost, rank, world, keeps_grid_states=keep), chunks=chunks)
+        assert s.K == chunks
         J = s.forward([s.local_slab(B), s.local_slab(U)])
         g = s.adjoint(adj)
         gB, gU = s.gather_full(g[0]), s.gather_full(g[1])
@@ -45,13 +46,14 @@ def _worker(rank, world, port, N, n, cost, adj, keep, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,world,cost,adj,keep", [(8, 2, "Final", "Discrete", True), (16, 2, "Integrated", "Discrete", False),
-                                                   (16, 2, "Final", "Continuous", True), (8, 4, "Final", "Discrete", False),
-                                                   (8, 4, "Integrated", "Continuous", True)])
-def test_slab_driver_matches_oracle(tmp_path, N, world, cost, adj, keep):
-    """keep = the forward solve keeps B_n on the grid side (the adjoint's inverse exchange then carries one field group)."""
+@pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [(8, 2, "Final", "Discrete", True, 1), (16, 2, "Integrated", "Discrete", False, 3),
+                                                          (16, 2, "Final", "Continuous", True, 2), (8, 4, "Final", "Discrete", False, 1),
+                                                          (8, 4, "Integrated", "Continuous", True, 1), (32, 2, "Final", "Discrete", True, 4)])
+def test_slab_driver_matches_oracle(tmp_path, N, world, cost, adj, keep, chunks):
+    """keep = the forward solve keeps B_n on the grid side (the adjoint's inverse exchange then carries one field group);
+    chunks = pipelining granularity of the local z slab (exchange buffers become [chunk][peer]...)."""
     out = str(tmp_path / "res.npy")
-    mp.spawn(_worker, args=(world, _free_port(), N, 3, cost, adj, keep, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, 3, cost, adj, keep, chunks, out), nprocs=world, join=True)
     r = np.load(out, allow_pickle=True).item()
     assert abs(r["J"] - r["Jo"]) <= 1e-10 * abs(r["Jo"])
     assert r["eB"] < 1e-10 and r["eU"] < 1e-10

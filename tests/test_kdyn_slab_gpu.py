@@ -44,9 +44,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, n, cost, adj, keep, out):
+def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
     sys.path.insert(0, ROOT)
     os.environ["SMO_KD_TYSTACK"] = "1" if keep else "0"
+    os.environ["SMO_SLAB_CHUNKS"] = str(chunks)
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -68,15 +69,15 @@ def _worker(rank, world, port, N, n, cost, adj, keep, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,world,cost,adj,keep", [(16, 2, "Final", "Discrete", True), (32, 4, "Integrated", "Discrete", False),
-                                                   (16, 2, "Final", "Continuous", True), (48, 4, "Final", "Discrete", True),
-                                                   (32, 2, "Final", "Discrete", False)])
-def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep):
+@pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [(16, 2, "Final", "Discrete", True, 1), (32, 4, "Integrated", "Discrete", False, 1),
+                                                          (16, 2, "Final", "Continuous", True, 2), (48, 4, "Final", "Discrete", True, 3),
+                                                          (32, 2, "Final", "Discrete", False, 4), (64, 2, "Integrated", "Continuous", True, 2)])
+def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep, chunks):
     import torch.multiprocessing as mp
     from oracle.kdyn import KDynOracle
     n = 3
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, chunks, out), nprocs=world, join=True)
     r = np.load(out)
     o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
     Jo = o.forward([r["B"], r["U"]]); goB, goU = o.adjoint([r["B"], r["U"]], adj)
@@ -85,9 +86,9 @@ def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep)
     assert abs(float(r["ip"]) - o.inner(r["B"], goB)) <= 1e-6 * abs(o.inner(r["B"], goB))
 
 
-def _nccl_worker(rank, port, N, n, out):
+def _nccl_worker(rank, port, N, n, chunks, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMO_SLAB_FORCE_EXCHANGE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMO_SLAB_FORCE_EXCHANGE="1", SMO_SLAB_CHUNKS=str(chunks))
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -101,7 +102,7 @@ def _nccl_worker(rank, port, N, n, out):
         J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
         g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
         s = SlabKDyn(N, 1., 1e-3, n, "Final")
-        assert s.force_exchange and not s.host_staged and s.buf_y.data_ptr() != s.buf_z.data_ptr()
+        assert s.force_exchange and not s.host_staged and s.buf_y.data_ptr() != s.buf_z.data_ptr() and s.K == chunks
         J1 = s.forward([s.local_slab(B), s.local_slab(U)])
         g1 = s.adjoint("Discrete")
         ip = s.inner(s.local_slab(B), g1[0])
@@ -111,13 +112,15 @@ def _nccl_worker(rank, port, N, n, out):
         dist.destroy_process_group()
 
 
-def test_rccl_call_path_on_one_rank(tmp_path):
+@pytest.mark.parametrize("chunks", [1, 2, 4])
+def test_rccl_call_path_on_one_rank(tmp_path, chunks):
     """The real RCCL collectives of the multi-GPU time loop (all_to_all_single on the solver's own HIP stream, all_reduce of J and
     <x,y>) on a one-rank process group, with the two exchange buffers kept apart: every transpose is a self-copy THROUGH the
-    collective, so the result must equal the monolithic single-GPU path bit for bit."""
+    collective, so the result must equal the monolithic single-GPU path bit for bit.  chunks > 1: the pipelined loop — asynchronous
+    collectives on the process group's stream overlapping the grid-side kernels of the other chunks."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "res.npz")
-    mp.spawn(_nccl_worker, args=(_free_port(), 32, 4, out), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(_free_port(), 32, 4, chunks, out), nprocs=1, join=True)
     r = np.load(out)
     assert float(r["J1"]) == float(r["J0"])
     assert float(r["eB"]) == 0.0 and float(r["eU"]) == 0.0
