@@ -128,9 +128,11 @@ class SlabKDyn:
         ops.set_buffers(self.buf_z, self.buf_y)
         self.adj_groups = 1 if ops.keeps_grid_states else 2
         # pipelining: the local z slab is cut into K chunks; the all-to-all of chunk k overlaps the grid-side kernels of the other chunks
-        # (the collectives run on the process group's own stream, the kernels on the solver's).  Default: 24 or more planes per chunk.
+        # (the collectives run on the process group's own stream, the kernels on the solver's).  Default: up to 4 chunks of at least 9216
+        # (y,z) points each — below that the grid-side kernels become launch-bound and chunking costs more than it hides (measured on
+        # one rank, profiles/r01_rccl_one_rank.jsonl).
         if chunks is None:
-            chunks = int(os.environ.get("SMO_SLAB_CHUNKS", "0")) or (max(1, min(4, self.Gzl // 24)) if self.world > 1 else 1)
+            chunks = int(os.environ.get("SMO_SLAB_CHUNKS", "0")) or (max(1, min(4, (self.G * self.Gzl) // 9216)) if self.world > 1 else 1)
         while chunks > 1 and (self.Gzl % chunks or (self.Gzl // chunks) % 2 or (self.G * (self.Gzl // chunks)) % 4):
             chunks -= 1
         self.K = chunks
