@@ -251,7 +251,7 @@ def bench_kdyn_slab(a, torch, rank, world):
            "slab_J_matches_single_gpu": bool(abs(J - float(J_single.item())) <= 1e-9 * abs(float(J_single.item()))),
            "J_single_gpu": float(J_single.item()),
            "parallelism": "slab x%d (kx / z decomposition, RCCL all-to-all between the z and y passes, %d field-group exchanges per "
-                          "step pair)" % (world, 4 + s.adj_groups),
+                          "step pair, %d pipelined z chunks)" % (world, 4 + s.adj_groups, s.K),
            "exchange_MB_sent_per_gpu_per_step_pair": (4 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
            "grid_states_kept_GB_per_gpu": s.ops.ctx.get(1) / 1e9}
     # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)

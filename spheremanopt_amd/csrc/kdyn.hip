@@ -57,9 +57,11 @@ __device__ __forceinline__ double wavenumber(int idx, const Geom& g) { return (i
 // the grid-side work on another):
 // z side: the peer index is the z block of `pos`; rt = ixl * m + iy is the local (kx, ky) row
 __device__ __forceinline__ size_t zs_off(int c, int rt, int pos, const Geom& g) {
+    const size_t row = ((size_t)c * (g.al * g.m) + rt) * g.Gzl;
+    if (g.Gzl == g.G) return row + pos;                                   // one slab, one chunk (uniform branch: no divisions)
     const int p = pos / g.Gzr, zl = pos - p * g.Gzr;
     const int k = zl / g.Gzl, zc = zl - k * g.Gzl;
-    return (size_t)k * g.cblk + (size_t)p * g.blk + ((size_t)c * (g.al * g.m) + rt) * g.Gzl + zc;
+    return (size_t)k * g.cblk + (size_t)p * g.blk + row + zc;
 }
 // caller-layout grid vector [3][G][G][Gzr]: offset of (c, x) at flat (y, z) index i of the chunk
 __device__ __forceinline__ size_t grid_off(int c, int x, size_t i, const Geom& g) {
