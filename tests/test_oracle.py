@@ -160,6 +160,17 @@ def test_poiseuille_transform_adjoints_and_taylor():
     assert abs(d - fd) < 2e-3 * abs(fd), (d, fd)
 
 
+def test_oracle_regression_poiseuille():
+    from oracle.poiseuille import PoiseuilleOracle
+    for sw in (0, 1):
+        g = _load("oracle_poiseuille_96x48_s%d.npz" % sw)
+        o = PoiseuilleOracle(96, 48, dt=5e-3, N_ITERS=40, s=sw, delta=0.3)
+        J = o.forward([g["X"]])
+        grad = o.adjoint([g["X"]])[0]
+        assert abs(J - g["J"]) <= 1e-12 * abs(g["J"])
+        assert np.linalg.norm(grad - g["grad"]) <= 1e-9 * np.linalg.norm(g["grad"])
+
+
 def test_kdyn_invariants():
     k = KDynOracle(12, Rm=1., dt=1e-2, N_ITERS=5)
     B = synthetic_field(k.G, 1); U = synthetic_field(k.G, 2)

@@ -1,7 +1,11 @@
 """Plane-Poiseuille optimal mixing on the device (through the C-ABI) against the oracle: the four transforms (dense MFMA GEMMs),
 the tau-operator time stepping, both cost functionals and the exact discrete adjoint (1e-6 relative on J and grad J)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import GOLDEN
 
 from spheremanopt_amd import _capi, poiseuille as pz
 from spheremanopt_amd.test_grad import taylor_table
@@ -59,6 +63,23 @@ def test_forward_adjoint_vs_oracle(Nx, Nz, n, s):
     ip = o.inner(X, go[0])
     assert abs(pz.Inner_Prod_Discrete(X, g[0], dom) - ip) <= RTOL * abs(ip)
     assert np.array_equal(pz.weightMatrixDisc(dom), o.W)
+    dom.drop_contexts()
+
+
+@pytest.mark.parametrize("sw", [0, 1])
+def test_against_committed_oracle_output(sw):
+    """96 x 48, 40 steps: expected values from the committed oracle run (tools/gen_golden_oracle.py)."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_poiseuille_96x48_s%d.npz" % sw))
+    dom = pz.PoiseuilleDomain(96, 48)
+    buf = pz.GEN_BUFFER(96, 48, dom, 40)
+    args = [dom, 500., 0.05, 40, buf, 5e-3, sw, 1., 0.3]
+    J = pz.FWD_Solve([gold["X"]], *args)
+    g = pz.ADJ_Solve([gold["X"]], *args)[0]
+    assert abs(J - gold["J"]) <= RTOL * abs(gold["J"])
+    assert rel(g, gold["grad"]) < RTOL
+    assert rel(buf['b_fwd'][:, :, -1], gold["b_last"]) < 1e-8
+    if sw == 0:
+        assert rel(buf['u_fwd'][:, :, -1], gold["u_last"]) < 1e-8
     dom.drop_contexts()
 
 

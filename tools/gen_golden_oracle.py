@@ -19,6 +19,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 from oracle.sh23 import SH23Oracle, synthetic_ic as sh_ic          # noqa: E402
 from oracle.kdyn import KDynOracle, synthetic_field                # noqa: E402
 from oracle import shb23                                           # noqa: E402
+from oracle.poiseuille import PoiseuilleOracle, synthetic_ic as pois_ic   # noqa: E402
 
 
 def sample_idx(n, k=64):
@@ -46,6 +47,15 @@ def main():
     np.savez(os.path.join(OUT, "oracle_shb23_c3.npz"), X=X, J=J, grad=g, stack_last=s.stack[:, -1],
              S_sample=s.S[::37, ::41], S_norm=np.linalg.norm(s.S))
     print("SHB23 C3: J=%.15e |g|=%.6e" % (J, np.linalg.norm(g)))
+
+    # Poiseuille (Discrete): 96 x 48, 40 steps, both cost functionals
+    for sw in (0, 1):
+        p = PoiseuilleOracle(96, 48, dt=5e-3, N_ITERS=40, s=sw, delta=0.3)
+        X = pois_ic(p, 42)
+        J = p.forward([X]); g = p.adjoint([X])[0]
+        np.savez(os.path.join(OUT, "oracle_poiseuille_96x48_s%d.npz" % sw), X=X, J=J, grad=g, u_last=p.stack[0, :p.ax, :, -1],
+                 b_last=p.stack[2, :p.ax, :, -1])
+        print("Poiseuille s=%d: J=%.15e |g|=%.6e" % (sw, J, np.linalg.norm(g)))
 
     # KDyn: reduced grid, both cost functions
     N, steps = a.kdyn_n, a.kdyn_steps
