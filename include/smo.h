@@ -52,7 +52,8 @@ enum { SMO_OK = 0, SMO_ERR_ARG = 1, SMO_ERR_NO_DEVICE = 2, SMO_ERR_HIP = 3, SMO_
        SMO_ERR_UNSUPPORTED = 6 };
 
 enum { SMO_SH23 = 1, SMO_SHB23 = 2, SMO_KDYN = 3, SMO_POIS = 4 }; /* smo_config.kind */
-enum { SMO_POIS_KINETIC = 0, SMO_POIS_MIXNORM = 1 };          /* smo_config.cost (POIS): the reference's switch s, FWD_Solve_Poiseuille.py:1761-1762 */
+enum { SMO_POIS_KINETIC = 0, SMO_POIS_MIXNORM = 1,              /* smo_config.cost (POIS): the reference's switch s (FWD_Solve_Poiseuille.py:1761-1762), Discrete */
+       SMO_POIS_CNTS_KINETIC = 2, SMO_POIS_CNTS_MIXNORM = 3 };   /* ... and the same two in the "Continuous" formulation (:614-775, :1161-1318) */
 enum { SMO_COST_FINAL = 0, SMO_COST_INTEGRATED = 1 };           /* smo_config.cost (KDYN) */
 enum { SMO_SHB_DISCRETE = 0, SMO_SHB_CONTINUOUS = 1 };          /* smo_config.cost (SHB23): formulation, FWD_Solve_SHB23.py:213-217 */
 enum { SMO_ADJ_DISCRETE = 0, SMO_ADJ_CONTINUOUS = 1 };          /* `adjoint_type` argument */
@@ -76,8 +77,9 @@ typedef struct smo_config {
      * states in between, one window at a time, during the adjoint sweep (+ (ckpt-1)/ckpt forward steps per adjoint step).
      * 1 = keep everything (the reference's N_SUB_ITERS = N_ITERS); 0 = smallest interval whose stack fits the free HBM. */
     int    ckpt;
-    /* second resolution / further parameters (POIS only; zero elsewhere): npts = Nx and npts2 = Nz as FWD_Solve_Discrete receives them
-     * (already scaled by 3/2, FWD_Solve_Poiseuille.py:1752-1755); x0,x1 = the x interval (0, 4 pi), z is (-1, 1); param = Reynolds,
+    /* second resolution / further parameters (POIS only; zero elsewhere): npts = Nx and npts2 = Nz as the solver receives them (Discrete:
+     * already scaled by 3/2, FWD_Solve_Poiseuille.py:1752-1755; Continuous: the mode counts, vectors then live on the 3/2 grid and
+     * smo_adjoint must be called with adjoint_type Continuous); x0,x1 = the x interval (0, 4 pi), z is (-1, 1); param = Reynolds,
      * param2 = Richardson, param3 = Prandtl (0 -> 1), param4 = delta of the base density profile (0 -> 0.25); cost = s. */
     int    npts2;
     double param2, param3, param4;

@@ -325,3 +325,181 @@ def synthetic_ic(oracle, seed, E0=0.02, prep_steps=5):
         u, v, rho, uz, vz, rz = o._apply(o.solve_map, [u / o.dt + NLu, v / o.dt + NLv, rho / o.dt + NLr])
     X = np.concatenate([np.real(o.transformInverse(o.DA * u)).ravel(), np.real(o.transformInverse(o.DA * v)).ravel()])
     return X * np.sqrt(E0 / o.inner(X, X))
+
+
+# -------------------------------------------------------------------------------------------------------------------------------------
+# "Continuous" formulation (the reference script's default Adjoint_type, FWD_Solve_Poiseuille.py:1728): Dedalus IVPs with SBDF1,
+# real Fourier x Chebyshev domain with dealias 3/2.  Restates FWD_Solve_Cnts (:614-775), ADJ_Solve_Cnts (:1161-1318), Inner_Prod_Cnts
+# (:264-280), Integrate_Field (:241-262) and Norm_and_Inverse_Second_Derivative (:1661-1696) — PARITY UNPINNED (Dedalus internals):
+#   * state: (a = Nx/2) x Nz complex T-coefficients (real Fourier basis, Nyquist dropped); products are formed on the
+#     (3Nx/2) x (3Nz/2) grid and truncated back (A.0-7); flat vectors live on that grid (Field_to_Vec with scales = dealias);
+#   * one SBDF1 step (A.0-5): (M/dt + L) X1 = M X0/dt + F(X0): the same tau solve map as the Discrete formulation, built for Nz modes;
+#     F uses the STATE variables uz, wz, bz (zero before the first step for uz, wz: the script only initialises u, w, b, bz);
+#   * integ(f) integrates the truncated series exactly: Lx * sum_{k even} f_{0,k} * 2/(1-k^2) -> quadrature weights on the grid;
+#   * the adjoint is the script's own adjoint PDE (an O(dt)-consistent approximation of the discrete gradient), N_ITERS steps,
+#     forward snapshots N, N-1, ..., 1 as coefficients of its right-hand side.
+# -------------------------------------------------------------------------------------------------------------------------------------
+class PoiseuilleCntsOracle:
+    def __init__(self, Nx=16, Nz=16, Re=500., Ri=0.05, dt=5e-3, N_ITERS=10, s=0, Prandtl=1., delta=0.125, Lx=4. * np.pi):
+        self.Nx, self.Nz, self.Re, self.Ri, self.Pe = int(Nx), int(Nz), float(Re), float(Ri), float(Re) * Prandtl
+        self.dt, self.N_ITERS, self.s, self.delta, self.Lx = float(dt), int(N_ITERS), int(s), float(delta), float(Lx)
+        self.a = (self.Nx - 1) // 2 + 1
+        self.Gx, self.Gz = 3 * self.Nx // 2, 3 * self.Nz // 2
+        self.k = 2. * np.pi * np.arange(self.a) / self.Lx
+        self.z = -np.cos(np.pi * (np.arange(self.Gz) + 0.5) / self.Gz)
+        self.V = self.Lx * 2.
+        self.Dz = cheb_diff(self.Nz)
+        j, i = np.arange(self.Nz)[:, None], np.arange(self.Gz)[None, :]
+        c = np.cos(np.pi * j * (2 * i + 1) / (2. * self.Gz)) * (-1.) ** j
+        self.Tf = (2. / self.Gz) * c * np.where(j == 0, 0.5, 1.)            # (Nz, Gz): grid line -> first Nz T coefficients
+        self.Ti = c.T.copy()                                                 # (Gz, Nz): T coefficients -> grid line
+        self.Wq = (cheb_integ(self.Nz) @ self.Tf) * (self.Lx / self.Gx)      # exact-integration weights of a truncated grid product
+        self._S, self._SA, self._SMN = {}, {}, {}
+        self.stack = None
+
+    def to_coeff(self, g):
+        F = np.fft.rfft(g, axis=0)[:self.a] / self.Gx
+        return F @ self.Tf.T
+
+    def to_grid(self, c):
+        F = np.zeros((self.Gx // 2 + 1, self.Gz), dtype=complex)
+        F[:self.a] = c @ self.Ti.T
+        F[0] = F[0].real
+        return np.fft.irfft(F, n=self.Gx, axis=0) * self.Gx
+
+    def integ_mean(self, g):
+        """(1/V) integ of a grid product, Dedalus style (truncate to the modes, integrate the series exactly)."""
+        return float(np.sum(g * self.Wq[None, :]) / self.V)
+
+    def split(self, X):
+        a1, a2 = np.split(np.asarray(X, dtype=float), 2)
+        return a1.reshape(self.Gx, self.Gz), a2.reshape(self.Gx, self.Gz)
+
+    def inner(self, x, y):
+        """Inner_Prod_Cnts (:264-280)."""
+        A, B = self.split(x); u, v = self.split(y)
+        return self.integ_mean(A * u + B * v)
+
+    def _maps(self, cache, n, adjoint):
+        if n not in cache:
+            h = PoiseuilleOracle.__new__(PoiseuilleOracle)
+            h.Nz, h.Lx, h.dt, h.Re, h.Pe, h.Ri, h.Dz, h._S = self.Nz, self.Lx, self.dt, self.Re, self.Pe, self.Ri, self.Dz, {}
+            cache[n] = solve_map_general(h, n, adjoint)
+        return cache[n]
+
+    def _apply(self, adjoint, fields):
+        cache = self._SA if adjoint else self._S
+        out = np.zeros((6, self.a, self.Nz), dtype=complex)
+        for n in range(self.a):
+            out[:, n] = (self._maps(cache, n, adjoint) @ np.concatenate([f[n] for f in fields])).reshape(6, self.Nz)
+        return out
+
+    def _mixnorm(self, rho):
+        h = PoiseuilleOracle.__new__(PoiseuilleOracle)
+        h.Nz, h.Lx, h.Dz, h._SMN = self.Nz, self.Lx, self.Dz, self._SMN
+        out = np.zeros((2, self.a, self.Nz), dtype=complex)
+        for n in range(self.a):
+            out[:, n] = (h.mixnorm_map(n) @ rho[n]).reshape(2, self.Nz)
+        return out
+
+    def forward(self, X):
+        X = X[0] if isinstance(X, (list, tuple)) else X
+        N, dt, ik, G, C = self.N_ITERS, self.dt, 1j * self.k[:, None], self.to_grid, self.to_coeff
+        ug0, wg0 = self.split(X)
+        u, w = C(ug0), C(wg0)
+        b = C(np.tile(-0.5 * erf(self.z / self.delta), (self.Gx, 1)))
+        bz = C(np.tile(-np.exp(-(self.z / self.delta) ** 2) / (self.delta * np.sqrt(np.pi)), (self.Gx, 1)))
+        uz, wz = np.zeros_like(u), np.zeros_like(u)
+        self.stack = np.zeros((3, self.a, self.Nz, N + 1), dtype=complex)
+        J = 0.
+        for n in range(N + 1):
+            self.stack[0, :, :, n], self.stack[1, :, :, n], self.stack[2, :, :, n] = u, w, b
+            ug, wg = G(u), G(w)
+            J += dt * self.integ_mean(ug * ug + wg * wg)
+            Fb = C(-(ug * G(ik * b) + wg * G(bz)))
+            Fu = C(-(ug * G(ik * u) + wg * G(uz)))
+            Fw = C(-(ug * G(ik * w) + wg * G(wz)))
+            u, w, b, uz, wz, bz = self._apply(False, [u / dt + Fu, w / dt + Fw, b / dt + Fb])
+        if self.s == 1:
+            psi, psiz = self._mixnorm(self.stack[2, :, :, N])
+            fx, fz = G(ik * psi), G(psiz)
+            return 0.5 * self.integ_mean(fx * fx + fz * fz)
+        return -0.5 * J
+
+    def adjoint(self, X=None):
+        N, dt, ik, G, C, Dz = self.N_ITERS, self.dt, 1j * self.k[:, None], self.to_grid, self.to_coeff, self.Dz
+        zero = np.zeros((self.a, self.Nz), dtype=complex)
+        ua, wa, ba, uza, wza, bza = (zero.copy() for _ in range(6))
+        if self.s == 1:
+            ba = -self._mixnorm(self.stack[2, :, :, N])[0]
+        idx = N
+        for _ in range(N):
+            uf, wf, bf = self.stack[0, :, :, idx], self.stack[1, :, :, idx], self.stack[2, :, :, idx]
+            idx -= 1
+            ufg, wfg = G(uf), G(wf)
+            uag, wag, bag = G(ua), G(wa), G(ba)
+            Fb = C(ufg * G(ik * ba) + wfg * G(bza))
+            Fu = C(-(uag * G(ik * uf) + wag * G(ik * wf)) + (ufg * G(ik * ua) + wfg * G(uza)) - bag * G(ik * bf) - (ufg if self.s == 0 else 0.))
+            Fw = C(-(uag * G(uf @ Dz.T) + wag * G(wf @ Dz.T)) + (ufg * G(ik * wa) + wfg * G(wza)) - bag * G(bf @ Dz.T) - (wfg if self.s == 0 else 0.))
+            ua, wa, ba, uza, wza, bza = self._apply(True, [ua / dt + Fu, wa / dt + Fw, ba / dt + Fb])
+        return [np.concatenate([G(ua).ravel(), G(wa).ravel()])]
+
+
+def solve_map_general(h, n, adjoint):
+    """Tau solve map of the forward (:465-500) or adjoint (:1217-1252) IVP for wavenumber n: (rhs_u, rhs_w, rhs_b) -> (u, w, b, uz, wz, bz).
+    The adjoint operator advects with -U, couples Ri*w into the b equation and Uz*u into the w equation."""
+    N, k, a0 = h.Nz, 2. * np.pi * n / h.Lx, 1. / h.dt
+    Pre, D, I = cheb_pre(N), h.Dz, np.eye(N)
+    M1 = cheb_mult(N, [0.5, 0., -0.5]); M2 = cheb_mult(N, [0., -2.])
+    sg = -1. if adjoint else 1.
+    U, Wv, R, UZ, WZ, RZ, P = (slice(i * N, (i + 1) * N) for i in range(7))
+    nv = 7 * N + (1 if n == 0 else 0)
+    A = np.zeros((nv, nv), dtype=complex); B = np.zeros((nv, 3 * N), dtype=complex)
+    row = 0
+
+    def diff_eq(blocks, rhs_slot=None):
+        nonlocal row
+        for var, mat in blocks:
+            A[row:row + N - 1, var] += (Pre @ mat)[:N - 1]
+        if rhs_slot is not None:
+            B[row:row + N - 1, rhs_slot * N:(rhs_slot + 1) * N] = Pre[:N - 1]
+        r0 = row; row += N - 1
+        return r0
+
+    adv = sg * 1j * k * M1
+    eq_u = [(U, (a0 + k * k / h.Re) * I + adv), (UZ, -D / h.Re), (P, -1j * k * I)]
+    eq_w = [(Wv, (a0 + k * k / h.Re) * I + adv), (WZ, -D / h.Re), (P, -D)]
+    eq_b = [(R, (a0 + k * k / h.Pe) * I + adv), (RZ, -D / h.Pe)]
+    if adjoint:
+        eq_w.append((U, M2)); eq_b.append((Wv, h.Ri * I))
+    else:
+        eq_u.append((Wv, M2)); eq_w.append((R, h.Ri * I))
+    diff_eq(eq_u, 0); diff_eq(eq_w, 1)
+    r3 = diff_eq(eq_b, 2)
+    if n == 0:
+        A[r3:r3 + N - 1, 7 * N] += Pre[:N - 1, 0]
+    A[row:row + N, U] += 1j * k * I; A[row:row + N, WZ] += I; row += N
+    diff_eq([(UZ, I), (U, -D)]); diff_eq([(WZ, I), (Wv, -D)]); diff_eq([(RZ, I), (R, -D)])
+    left, right, integ = (-1.) ** np.arange(N), np.ones(N), cheb_integ(N)
+    for var, fun in ((RZ, left), (RZ, right), (U, left), (Wv, left), (U, right), ((Wv, right) if n != 0 else (P, integ))):
+        A[row, var] = fun; row += 1
+    if n == 0:
+        A[row, R] = integ; row += 1
+    assert row == nv
+    return np.linalg.solve(A, B)[:6 * N]
+
+
+def synthetic_ic_cnts(oracle, seed, E0=0.02, prep_steps=5):
+    """Continuous-formulation counterpart of synthetic_ic: band-limited stream-function noise, a few forward steps, scaled to <U,U> = E0."""
+    o = oracle
+    psi = o.to_coeff(np.random.RandomState(seed).standard_normal((o.Gx, o.Gz)))
+    psi = psi * ((np.arange(o.a) <= o.a // 2)[:, None] & (np.arange(o.Nz) < o.Nz // 2)[None, :])
+    ik = 1j * o.k[:, None]
+    u, w = -(psi @ o.Dz.T), ik * psi
+    sc = 1e-2 / np.abs(o.to_grid(u)).max()
+    u, w = sc * u, sc * w
+    zero = np.zeros_like(u)
+    for _ in range(prep_steps):
+        u, w, b, uz, wz, bz = o._apply(False, [u / o.dt, w / o.dt, zero])
+    X = np.concatenate([o.to_grid(u).ravel(), o.to_grid(w).ravel()])
+    return X * np.sqrt(E0 / o.inner(X, X))

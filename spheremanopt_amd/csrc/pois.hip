@@ -341,22 +341,26 @@ static int banded_solve(int n, int nb, int win, std::vector<cd>& A, int m, std::
 // Unknown index 7*mode + var (var: u v rho uz vz rhoz p) [+ Fb at the end for n = 0]; rows: for mode m < N-1 the seven equations
 // (three tau-reduced evolution equations, continuity, three tau-reduced derivative definitions), then continuity of mode N-1, the
 // six boundary / gauge rows [and integ(rho) = 0 for n = 0].
-static int build_solve_map(const Cheb& ch, int n, double k, double a0, double Re, double Pe, double Ri, std::vector<cd>& S) {
+// adjoint = the operator of the script's adjoint IVP (POIS:1217-1252): advection by -U, Ri*w coupled into the density equation and
+// Uz*u into the w equation (instead of Ri*rho into w and Uz*w into u).
+static int build_solve_map(const Cheb& ch, int n, double k, double a0, double Re, double Pe, double Ri, std::vector<cd>& S, bool adjoint = false) {
     const int N = ch.N, nv = 7 * N + (n == 0 ? 1 : 0), nb = 7 * (N - 1);
     std::vector<cd> A((size_t)nv * nv, cd(0)), B((size_t)nv * 3 * N, cd(0));
     auto at = [&](int r, int c) -> cd& { return A[(size_t)r * nv + c]; };
     enum { U = 0, V = 1, R = 2, UZ = 3, VZ = 4, RZ = 5, P = 6 };
-    const cd ik(0.0, k);
+    const cd ik(0.0, k), adv(0.0, adjoint ? -k : k);
     for (int m = 0; m < N - 1; ++m) {
         const int r0 = 7 * m;
         for (int c = std::max(0, m - 2); c < std::min(N, m + 5); ++c) {
             const double pre = ch.Pre[(size_t)m * N + c], pm1 = ch.pre_times(ch.M1, m, c), pm2 = ch.pre_times(ch.M2, m, c),
                          pd = ch.PD[(size_t)m * N + c];
-            at(r0 + 0, 7 * c + U) += (a0 + k * k / Re) * pre + ik * pm1;  at(r0 + 0, 7 * c + UZ) += -pd / Re;
-            at(r0 + 0, 7 * c + P) += ik * pre;                            at(r0 + 0, 7 * c + V) += pm2;
-            at(r0 + 1, 7 * c + V) += (a0 + k * k / Re) * pre + ik * pm1;  at(r0 + 1, 7 * c + VZ) += -pd / Re;
-            at(r0 + 1, 7 * c + P) += pd;                                  at(r0 + 1, 7 * c + R) += Ri * pre;
-            at(r0 + 2, 7 * c + R) += (a0 + k * k / Pe) * pre + ik * pm1;  at(r0 + 2, 7 * c + RZ) += -pd / Pe;
+            at(r0 + 0, 7 * c + U) += (a0 + k * k / Re) * pre + adv * pm1;  at(r0 + 0, 7 * c + UZ) += -pd / Re;
+            at(r0 + 0, 7 * c + P) += ik * pre;
+            at(r0 + 1, 7 * c + V) += (a0 + k * k / Re) * pre + adv * pm1;  at(r0 + 1, 7 * c + VZ) += -pd / Re;
+            at(r0 + 1, 7 * c + P) += pd;
+            at(r0 + 2, 7 * c + R) += (a0 + k * k / Pe) * pre + adv * pm1;  at(r0 + 2, 7 * c + RZ) += -pd / Pe;
+            if (!adjoint) { at(r0 + 0, 7 * c + V) += pm2;  at(r0 + 1, 7 * c + R) += Ri * pre; }
+            else          { at(r0 + 1, 7 * c + U) += pm2;  at(r0 + 2, 7 * c + V) += Ri * pre; }
             at(r0 + 4, 7 * c + UZ) += pre;  at(r0 + 4, 7 * c + U) += -pd;
             at(r0 + 5, 7 * c + VZ) += pre;  at(r0 + 5, 7 * c + V) += -pd;
             at(r0 + 6, 7 * c + RZ) += pre;  at(r0 + 6, 7 * c + R) += -pd;
@@ -848,8 +852,327 @@ public:
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------
+// "Continuous" formulation (the script's default Adjoint_type, POIS:1728): the Dedalus IVPs of FWD_Solve_Cnts (:614-775) and
+// ADJ_Solve_Cnts (:1161-1318) with SBDF1 on Nx x Nz modes, products on the 3/2 grid, exact-integration inner product (:241-280).
+// Same kernels as above; the z matrices are rectangular (Nz modes <-> 3Nz/2 grid points) and the adjoint has its own tau operator.
+// ---------------------------------------------------------------------------------------------------------
+// right-hand side of the adjoint IVP on the grid (POIS:1217-1226):
+//   gr = [uf, wf, ufx, wfx, bfx, ufz, wfz, bfz, ua, wa, ba, uax, wax, bax, uza, wza, bza]  ->  pr = [Fu, Fw, Fb]
+__global__ __launch_bounds__(256) void pois_cnts_adj_rhs(const double* __restrict__ gr, double* __restrict__ pr, int kinetic, size_t nG) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nG; i += (size_t)gridDim.x * 256) {
+        const double uf = gr[i], wf = gr[nG + i], ufx = gr[2 * nG + i], wfx = gr[3 * nG + i], bfx = gr[4 * nG + i], ufz = gr[5 * nG + i],
+                     wfz = gr[6 * nG + i], bfz = gr[7 * nG + i], ua = gr[8 * nG + i], wa = gr[9 * nG + i], ba = gr[10 * nG + i],
+                     uax = gr[11 * nG + i], wax = gr[12 * nG + i], bax = gr[13 * nG + i], uza = gr[14 * nG + i], wza = gr[15 * nG + i],
+                     bza = gr[16 * nG + i];
+        pr[i] = -(ua * ufx + wa * wfx) + (uf * uax + wf * uza) - ba * bfx - (kinetic ? uf : 0.0);
+        pr[nG + i] = -(ua * ufz + wa * wfz) + (uf * wax + wf * wza) - ba * bfz - (kinetic ? wf : 0.0);
+        pr[2 * nG + i] = uf * bax + wf * bza;
+    }
+}
+
+class PoisCnts : public Context {
+public:
+    explicit PoisCnts(const smo_config& c) { cfg = c; }
+    int Nxm = 0, Nz = 0, a = 0, Gx = 0, Gz = 0, s_cost = 0;
+    double Lx = 0, k1 = 0, V = 0;
+    size_t nC = 0, nL = 0, nG = 0;                       // coefficient field [2a][Nz], z-transformed lines [2a][Gz], grid [Gx][Gz]
+    double *B_ZiT = nullptr, *B_DZiT = nullptr, *B_ZfT = nullptr, *B_DzT = nullptr, *A_Xi = nullptr, *A_XiD = nullptr, *A_Xf = nullptr;
+    double *d_Wq = nullptr, *d_b0 = nullptr, *d_bz0 = nullptr, *d_q = nullptr, *d_X3 = nullptr;
+    double2 *d_S = nullptr, *d_SA = nullptr, *d_SMN = nullptr;
+    double *S6 = nullptr, *A6 = nullptr, *R3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr, *HC = nullptr,
+           *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
+    std::vector<double> h_part;
+    int k_gemm = -1, k_apply = -1, k_point = -1;
+    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
+    Phase F0x, F0z, Fz, Fx, Fxf, Fzf, F1d, A1d, M1z, M1x, Az, Ax, Gz2, Gx2;
+
+    int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
+        p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
+        return pool.upload(&p.d, v, stream);
+    }
+    int run(const Phase& p) {
+        ScopedTimer t(timing, k_gemm, stream);
+        hipLaunchKernelGGL(pois_gemm, dim3((p.N + 63) / 64, (p.M + 63) / 64, p.n), dim3(256), 0, stream, p.d, p.M, p.N, p.K);
+        return SMO_OK;
+    }
+    int apply(const double2* S, const double* in, double* out, double* xout, int nin, int nout, int xo) {
+        const long long rows = (long long)a * (nout * Nz + xo);
+        ScopedTimer t(timing, k_apply, stream);
+        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, (const double*)nullptr, out, xout, (double*)nullptr, a,
+                           a, Nz, nin, 0, nout, xo);
+        return SMO_OK;
+    }
+    dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
+    double* snap(int n) { return d_stack + (size_t)n * 3 * nC; }
+
+    int init() override {
+        Nxm = cfg.npts; Nz = cfg.npts2; s_cost = cfg.cost - 2;
+        if (cfg.batch != 1 || cfg.world != 1) { set_error("POIS: batch and world must be 1"); return SMO_ERR_ARG; }
+        if (Nxm < 8 || Nz < 8 || Nxm > 512 || Nz > 256 || Nxm % 4 != 0 || Nz % 2 != 0) {
+            set_error("POIS (Continuous): need npts (Nx modes) a multiple of 4 in [8, 512] and npts2 (Nz modes) even in [8, 256], got %d x %d", Nxm, Nz);
+            return SMO_ERR_UNSUPPORTED;
+        }
+        Lx = cfg.x1 - cfg.x0; k1 = 2.0 * M_PI / Lx; V = Lx * 2.0;
+        const double Re = cfg.param, Ri = cfg.param2, Pe = cfg.param * (cfg.param3 > 0 ? cfg.param3 : 1.0), delta = cfg.param4 > 0 ? cfg.param4 : 0.25;
+        a = (Nxm - 1) / 2 + 1; Gx = 3 * Nxm / 2; Gz = 3 * Nz / 2;
+        nC = (size_t)2 * a * Nz; nL = (size_t)2 * a * Gz; nG = (size_t)Gx * Gz;
+        n_comp = 1;
+        vec_len = 2 * nG;
+        snapshot_doubles = 3 * nC;
+        stack_bytes = (size_t)(cfg.n_iters + 1) * 3 * nC * sizeof(double);
+        SMO_TRY(base_init());
+        const int N = Nz;
+        Cheb ch(N);
+        // rectangular z matrices: Tf (N x Gz) grid line -> first N T coefficients, Ti (Gz x N) back
+        std::vector<double> Tf((size_t)N * Gz), Ti((size_t)Gz * N), z(Gz), Wq(Gz, 0.0);
+        for (int i = 0; i < Gz; ++i) z[i] = -std::cos(M_PI * (i + 0.5) / Gz);
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < Gz; ++i) {
+                const double c = std::cos(M_PI * j * (2 * i + 1) / (2.0 * Gz)), sg = (j & 1) ? -1.0 : 1.0;
+                Tf[(size_t)j * Gz + i] = (2.0 / Gz) * c * (j == 0 ? 0.5 : 1.0) * sg;
+                Ti[(size_t)i * N + j] = sg * c;
+            }
+        for (int i = 0; i < Gz; ++i) {                                  // exact integral of the truncated series, as a quadrature on the grid
+            double w = 0.0;
+            for (int j = 0; j < N; j += 2) w += ch.integ[j] * Tf[(size_t)j * Gz + i];
+            Wq[i] = w * (Lx / Gx);
+        }
+        std::vector<double> ZiT((size_t)N * Gz), DZiT((size_t)N * Gz, 0.0), ZfT((size_t)Gz * N), DzT((size_t)N * N);
+        for (int j = 0; j < N; ++j) for (int i = 0; i < Gz; ++i) { ZiT[(size_t)j * Gz + i] = Ti[(size_t)i * N + j]; ZfT[(size_t)i * N + j] = Tf[(size_t)j * Gz + i]; }
+        for (int j = 0; j < N; ++j) for (int m = 0; m < N; ++m) {
+            DzT[(size_t)m * N + j] = ch.D[(size_t)j * N + m];
+            const double d = ch.D[(size_t)m * N + j];                   // (Ti Dz)[z][j] = sum_m Ti[z][m] Dz[m][j]
+            if (d != 0.0) for (int i = 0; i < Gz; ++i) DZiT[(size_t)j * Gz + i] += Ti[(size_t)i * N + m] * d;
+        }
+        SMO_TRY(pool.upload(&B_ZiT, ZiT, stream)); SMO_TRY(pool.upload(&B_DZiT, DZiT, stream)); SMO_TRY(pool.upload(&B_ZfT, ZfT, stream));
+        SMO_TRY(pool.upload(&B_DzT, DzT, stream)); SMO_TRY(pool.upload(&d_Wq, Wq, stream));
+        {
+            std::vector<double> q(N, 0.0);
+            for (int j = N - 1; j >= 1; j -= 2) q[j] = 1.0;
+            if ((N - 1) % 2 == 0) q[0] = 0.5;
+            SMO_TRY(pool.upload(&d_q, q, stream));
+        }
+        std::vector<double> Xi((size_t)Gx * 2 * a), XiD(Xi.size()), Xf((size_t)2 * a * Gx);
+        for (int x = 0; x < Gx; ++x)
+            for (int n = 0; n < a; ++n) {
+                const double k = k1 * n, ph = 2.0 * M_PI * (double)((long long)n * x % Gx) / Gx, c = std::cos(ph), sn = std::sin(ph), w = n == 0 ? 1.0 : 2.0;
+                Xi[(size_t)x * 2 * a + 2 * n] = w * c;          Xi[(size_t)x * 2 * a + 2 * n + 1] = -w * sn;
+                XiD[(size_t)x * 2 * a + 2 * n] = -w * k * sn;   XiD[(size_t)x * 2 * a + 2 * n + 1] = -w * k * c;
+                Xf[(size_t)(2 * n) * Gx + x] = c / Gx;          Xf[(size_t)(2 * n + 1) * Gx + x] = -sn / Gx;
+            }
+        SMO_TRY(pool.upload(&A_Xi, Xi, stream)); SMO_TRY(pool.upload(&A_XiD, XiD, stream)); SMO_TRY(pool.upload(&A_Xf, Xf, stream));
+        {
+            std::vector<double> b0(nC, 0.0), bz0(nC, 0.0);
+            for (int j = 0; j < N; ++j) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int i = 0; i < Gz; ++i) {
+                    s0 += Tf[(size_t)j * Gz + i] * (-0.5 * std::erf(z[i] / delta));
+                    s1 += Tf[(size_t)j * Gz + i] * (-std::exp(-(z[i] / delta) * (z[i] / delta)) / (delta * std::sqrt(M_PI)));
+                }
+                b0[j] = s0; bz0[j] = s1;
+            }
+            SMO_TRY(pool.upload(&d_b0, b0, stream)); SMO_TRY(pool.upload(&d_bz0, bz0, stream));
+        }
+        {
+            const size_t sz = (size_t)(3 * N + 3) * 3 * N, szm = (size_t)2 * N * N;
+            std::vector<cd> S((size_t)a * sz), SA((size_t)a * sz), SM((size_t)a * szm);
+            std::vector<int> rc(a, SMO_OK);
+            std::vector<std::string> msg(a);
+            const int nthr = std::max(1, std::min<int>(a, (int)std::thread::hardware_concurrency()));
+            auto reduce = [&](const std::vector<cd>& s, cd* dst) {
+                std::copy(s.begin(), s.begin() + (size_t)3 * N * 3 * N, dst);
+                for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * 3 * N], &s[((size_t)(3 + f) * N + N - 1) * 3 * N] + 3 * N, dst + (size_t)(3 * N + f) * 3 * N);
+            };
+            auto work = [&](int t) {
+                for (int n = t; n < a; n += nthr) {
+                    std::vector<cd> s, sa, sm;
+                    int r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, s, false);
+                    if (r == SMO_OK) r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, sa, true);
+                    if (r == SMO_OK) r = build_mixnorm_map(ch, n, k1 * n, sm);
+                    if (r != SMO_OK) { rc[n] = r; msg[n] = last_error(); continue; }
+                    reduce(s, &S[(size_t)n * sz]); reduce(sa, &SA[(size_t)n * sz]);
+                    std::copy(sm.begin(), sm.end(), SM.begin() + (size_t)n * szm);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+            for (auto& t : th) t.join();
+            for (int n = 0; n < a; ++n) if (rc[n] != SMO_OK) { set_error("%s (wavenumber %d)", msg[n].c_str(), n); return rc[n]; }
+            auto up = [&](double2** p, const std::vector<cd>& h) -> int {
+                SMO_TRY(pool.alloc(p, h.size()));
+                SMO_HIP(hipMemcpyAsync(*p, h.data(), h.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+                SMO_HIP(hipStreamSynchronize(stream));
+                return SMO_OK;
+            };
+            SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SA, SA)); SMO_TRY(up(&d_SMN, SM));
+        }
+        SMO_TRY(pool.alloc(&S6, 6 * nC)); SMO_TRY(pool.alloc(&A6, 6 * nC)); SMO_TRY(pool.alloc(&R3, 3 * nC)); SMO_TRY(pool.alloc(&cur3, 3 * nC));
+        SMO_TRY(pool.alloc(&G1, 12 * nL)); SMO_TRY(pool.alloc(&GR, 17 * nG)); SMO_TRY(pool.alloc(&PR, 3 * nG)); SMO_TRY(pool.alloc(&H, 3 * nL));
+        SMO_TRY(pool.alloc(&HC, 3 * nC)); SMO_TRY(pool.alloc(&MN, 2 * nC)); SMO_TRY(pool.alloc(&d_X3, (size_t)2 * a * 3));
+        SMO_TRY(pool.alloc(&d_stack, (size_t)(cfg.n_iters + 1) * 3 * nC));
+        SMO_TRY(pool.alloc(&d_part, (size_t)(cfg.n_iters + 2) * NPART));
+        h_part.resize((size_t)(cfg.n_iters + 2) * NPART);
+        const int M2a = 2 * a;
+        auto c_ = [&](double* base, int i) { return base + (size_t)i * nC; };
+        auto l_ = [&](double* base, int i) { return base + (size_t)i * nL; };
+        auto g_ = [&](double* base, int i) { return base + (size_t)i * nG; };
+        SMO_TRY(make_phase(F0x, M2a, Gz, Gx, {{A_Xf, g_(GR, 0), l_(H, 0)}, {A_Xf, g_(GR, 1), l_(H, 1)}}));
+        SMO_TRY(make_phase(F0z, M2a, Nz, Gz, {{l_(H, 0), B_ZfT, c_(S6, 0)}, {l_(H, 1), B_ZfT, c_(S6, 1)}}));
+        { std::vector<GemmDesc> v; for (int f = 0; f < 6; ++f) v.push_back({c_(S6, f), B_ZiT, l_(G1, f)}); SMO_TRY(make_phase(Fz, M2a, Gz, Nz, v)); }
+        // grids [u, ux, uz, w, wx, wz, bx, bz] from the lines of [u, w, b, uz, wz, bz]
+        SMO_TRY(make_phase(Fx, Gx, Gz, M2a, {{A_Xi, l_(G1, 0), g_(GR, 0)}, {A_XiD, l_(G1, 0), g_(GR, 1)}, {A_Xi, l_(G1, 3), g_(GR, 2)},
+                                             {A_Xi, l_(G1, 1), g_(GR, 3)}, {A_XiD, l_(G1, 1), g_(GR, 4)}, {A_Xi, l_(G1, 4), g_(GR, 5)},
+                                             {A_XiD, l_(G1, 2), g_(GR, 6)}, {A_Xi, l_(G1, 5), g_(GR, 7)}}));
+        { std::vector<GemmDesc> v, w, d1, d2;
+          for (int f = 0; f < 3; ++f) { v.push_back({A_Xf, g_(PR, f), l_(H, f)}); w.push_back({l_(H, f), B_ZfT, c_(HC, f)});
+                                        d1.push_back({c_(S6, f), B_DzT, c_(S6, 3 + f)}); d2.push_back({c_(A6, f), B_DzT, c_(A6, 3 + f)}); }
+          SMO_TRY(make_phase(Fxf, M2a, Gz, Gx, v)); SMO_TRY(make_phase(Fzf, M2a, Nz, Gz, w));
+          SMO_TRY(make_phase(F1d, M2a, Nz, Nz, d1)); SMO_TRY(make_phase(A1d, M2a, Nz, Nz, d2)); }
+        SMO_TRY(make_phase(M1z, M2a, Gz, Nz, {{c_(MN, 0), B_ZiT, l_(G1, 0)}, {c_(MN, 1), B_ZiT, l_(G1, 1)}}));
+        SMO_TRY(make_phase(M1x, Gx, Gz, M2a, {{A_XiD, l_(G1, 0), g_(GR, 0)}, {A_Xi, l_(G1, 1), g_(GR, 1)}}));
+        // adjoint step: lines of [uf, wf, bf | dz uf, dz wf, dz bf | ua, wa, ba, uza, wza, bza]
+        { std::vector<GemmDesc> v;
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_ZiT, l_(G1, f)});
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_DZiT, l_(G1, 3 + f)});
+          for (int f = 0; f < 6; ++f) v.push_back({c_(A6, f), B_ZiT, l_(G1, 6 + f)});
+          SMO_TRY(make_phase(Az, M2a, Gz, Nz, v)); }
+        SMO_TRY(make_phase(Ax, Gx, Gz, M2a, {{A_Xi, l_(G1, 0), g_(GR, 0)}, {A_Xi, l_(G1, 1), g_(GR, 1)}, {A_XiD, l_(G1, 0), g_(GR, 2)},
+                                             {A_XiD, l_(G1, 1), g_(GR, 3)}, {A_XiD, l_(G1, 2), g_(GR, 4)}, {A_Xi, l_(G1, 3), g_(GR, 5)},
+                                             {A_Xi, l_(G1, 4), g_(GR, 6)}, {A_Xi, l_(G1, 5), g_(GR, 7)}, {A_Xi, l_(G1, 6), g_(GR, 8)},
+                                             {A_Xi, l_(G1, 7), g_(GR, 9)}, {A_Xi, l_(G1, 8), g_(GR, 10)}, {A_XiD, l_(G1, 6), g_(GR, 11)},
+                                             {A_XiD, l_(G1, 7), g_(GR, 12)}, {A_XiD, l_(G1, 8), g_(GR, 13)}, {A_Xi, l_(G1, 9), g_(GR, 14)},
+                                             {A_Xi, l_(G1, 10), g_(GR, 15)}, {A_Xi, l_(G1, 11), g_(GR, 16)}}));
+        SMO_TRY(make_phase(Gz2, M2a, Gz, Nz, {{c_(A6, 0), B_ZiT, l_(G1, 0)}, {c_(A6, 1), B_ZiT, l_(G1, 1)}}));
+        SMO_TRY(make_phase(Gx2, Gx, Gz, M2a, {{A_Xi, l_(G1, 0), g_(GR, 0)}, {A_Xi, l_(G1, 1), g_(GR, 1)}}));
+        k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
+        k_apply = timing.add_class("pois_apply (tau operator, batched complex GEMV)", (double)a * (3 * N + 3) * 3 * N * 16.0);
+        k_point = timing.add_class("pois pointwise", 0.0);
+        return SMO_OK;
+    }
+
+    int sum_partials(int row0, int nrows, double* out) {
+        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part + (size_t)row0 * NPART, (size_t)nrows * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        for (int r = 0; r < nrows; ++r) { double s = 0.0; for (int i = 0; i < NPART; ++i) s += h_part[(size_t)r * NPART + i]; out[r] = s; }
+        return SMO_OK;
+    }
+    // one SBDF1 step of a 6-field state with the operator S: rhs grids PR[0..2] -> state (u, w, b, uz, wz, bz)
+    int advance(double* state, const double2* S, const Phase& deriv) {
+        SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));
+        {
+            ScopedTimer t(timing, k_point, stream);
+            hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, state, 1.0 / cfg.dt, HC, 3 * nC);
+        }
+        SMO_TRY(apply(S, R3, state, d_X3, 3, 3, 3));
+        SMO_TRY(run(deriv));
+        ScopedTimer t(timing, k_point, stream);
+        hipLaunchKernelGGL(pois_rank1_add, pw_grid(3 * nC), dim3(256), 0, stream, state + 3 * nC, d_X3, d_q, 2 * a, Nz);
+        return SMO_OK;
+    }
+    // psi, psiz of snapshot N's density into MN; grids dx psi, psiz into GR[0], GR[1]
+    int mixnorm_fields() {
+        SMO_TRY(apply(d_SMN, snap(cfg.n_iters) + 2 * nC, MN, nullptr, 1, 2, 0));
+        SMO_TRY(run(M1z));
+        return run(M1x);
+    }
+
+    int forward_dev(const double* const* X, double* J) override {
+        have_forward = false;
+        const int N = cfg.n_iters;
+        SMO_HIP(hipMemcpyAsync(GR, X[0], 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipMemsetAsync(S6, 0, 6 * nC * sizeof(double), stream));                  // uz = wz = 0 before the first step (POIS:653-657)
+        SMO_TRY(run(F0x)); SMO_TRY(run(F0z));
+        SMO_HIP(hipMemcpyAsync(S6 + 2 * nC, d_b0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_bz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        for (int n = 0; n <= N; ++n) {                                                 // N_ITERS + 1 steps, like the script (stop_iteration = N_ITERS+1)
+            SMO_HIP(hipMemcpyAsync(snap(n), S6, 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_TRY(run(Fz)); SMO_TRY(run(Fx));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_nl, dim3(NPART), dim3(256), 0, stream, GR, PR, d_Wq, d_part + (size_t)n * NPART, nG, Gz);
+            }
+            SMO_TRY(advance(S6, d_S, F1d));
+        }
+        double cost = 0.0;
+        if (s_cost == 1) {
+            SMO_TRY(mixnorm_fields());
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_wsq, dim3(NPART), dim3(256), 0, stream, GR, GR + nG, d_Wq, d_part + (size_t)(N + 1) * NPART, (double*)nullptr,
+                                   (double*)nullptr, 0.0, nG, Gz);
+            }
+            double e = 0.0;
+            SMO_TRY(sum_partials(N + 1, 1, &e));
+            cost = 0.5 * e / V;
+        } else {
+            std::vector<double> e(N + 1);
+            SMO_TRY(sum_partials(0, N + 1, e.data()));
+            double ke = 0.0;
+            for (int n = 0; n <= N; ++n) ke += cfg.dt * e[n] / V;
+            cost = -0.5 * ke;
+        }
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        *J = cost;
+        have_forward = true;
+        return SMO_OK;
+    }
+
+    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        if (adjoint_type != SMO_ADJ_CONTINUOUS) { set_error("POIS: this context was created for the Continuous formulation (cost >= 2)"); return SMO_ERR_ARG; }
+        const int N = cfg.n_iters;
+        SMO_HIP(hipMemsetAsync(A6, 0, 6 * nC * sizeof(double), stream));
+        if (s_cost == 1) {                                                             // b_adj(0) = -psi (POIS:1268-1272)
+            SMO_TRY(apply(d_SMN, snap(N) + 2 * nC, MN, nullptr, 1, 2, 0));
+            ScopedTimer t(timing, k_point, stream);
+            hipLaunchKernelGGL(pois_axpy, pw_grid(nC), dim3(256), 0, stream, A6 + 2 * nC, MN, -1.0, (const double*)nullptr, nC);
+        }
+        for (int idx = N; idx >= 1; --idx) {
+            SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_TRY(run(Az)); SMO_TRY(run(Ax));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_cnts_adj_rhs, pw_grid(nG), dim3(256), 0, stream, GR, PR, s_cost == 0 ? 1 : 0, nG);
+            }
+            SMO_TRY(advance(A6, d_SA, A1d));
+        }
+        SMO_TRY(run(Gz2)); SMO_TRY(run(Gx2));
+        SMO_HIP(hipMemcpyAsync(grad[0], GR, 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
+    int inner_dev(const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(pois_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_Wq, d_part + (size_t)(cfg.n_iters + 1) * NPART, 2 * nG, Gz);
+        SMO_HIP(hipGetLastError());
+        double s = 0.0;
+        SMO_TRY(sum_partials(cfg.n_iters + 1, 1, &s));
+        *out = s / V;
+        return SMO_OK;
+    }
+
+    int snapshot_read(int, int index, double* out) override {
+        std::vector<double> h(3 * nC);
+        SMO_HIP(hipMemcpyAsync(h.data(), snap(index), 3 * nC * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        for (int f = 0; f < 3; ++f)
+            for (int n = 0; n < a; ++n)
+                for (int j = 0; j < Nz; ++j) {
+                    out[(((size_t)f * a + n) * Nz + j) * 2] = h[(size_t)f * nC + ((size_t)2 * n) * Nz + j];
+                    out[(((size_t)f * a + n) * Nz + j) * 2 + 1] = h[(size_t)f * nC + ((size_t)2 * n + 1) * Nz + j];
+                }
+        return SMO_OK;
+    }
+};
+
 }  // namespace
 
-Context* make_pois(const smo_config& cfg) { return new Pois(cfg); }
+Context* make_pois(const smo_config& cfg) {
+    if (cfg.cost >= 2 && cfg.cost <= 3) return new PoisCnts(cfg);      // Continuous formulation: s = cost - 2
+    return new Pois(cfg);
+}
 
 }  // namespace smo

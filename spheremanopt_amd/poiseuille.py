@@ -40,10 +40,13 @@ class SnapshotStack:
 
 
 class PoiseuilleDomain:
-    """Geometry + owner of the device contexts (one per parameter set)."""
+    """Geometry + owner of the device contexts (one per parameter set).  continuous=True: the "Continuous" formulation — Nx, Nz are
+    then the MODE counts of the Dedalus domain (dealias 3/2) and the flat vectors live on the (3Nx/2, 3Nz/2) grid."""
 
-    def __init__(self, Nx, Nz, X_domain=(0., 4. * np.pi), device=0):
+    def __init__(self, Nx, Nz, X_domain=(0., 4. * np.pi), device=0, continuous=False):
         self.Nx, self.Nz, self.interval, self.device = int(Nx), int(Nz), (float(X_domain[0]), float(X_domain[1])), device
+        self.continuous = bool(continuous)
+        self.gshape = (3 * self.Nx // 2, 3 * self.Nz // 2) if self.continuous else (self.Nx, self.Nz)
         self.a = (self.Nx - 1) // 2 + 1                 # non-negative x wavenumbers carried (n = 0..kmax)
         self.ada = (2 * self.Nx // 3) // 2              # de-aliased ones (n < ada)
         self.hypervolume = (self.interval[1] - self.interval[0]) * 2.
@@ -57,7 +60,8 @@ class PoiseuilleDomain:
     def context(self, Reynolds, Richardson, N_ITERS, dt, s, Prandtl, delta):
         key = (float(Reynolds), float(Richardson), int(N_ITERS), float(dt), int(s), float(Prandtl), float(delta))
         if key not in self._ctx:
-            self._ctx[key] = _capi.Context(_capi.SMO_POIS, self.Nx, self.interval, dt, N_ITERS, Reynolds, cost=int(s), device=self.device,
+            self._ctx[key] = _capi.Context(_capi.SMO_POIS, self.Nx, self.interval, dt, N_ITERS, Reynolds,
+                                           cost=int(s) + (2 if self.continuous else 0), device=self.device,
                                            npts2=self.Nz, param2=Richardson, param3=Prandtl, param4=delta)
         return self._ctx[key]
 
@@ -162,6 +166,36 @@ def Generate_IC(Nx, Nz, X_domain=(0., 4. * np.pi), Z_domain=(-1., 1.), E_0=0.02,
         snap[:, :, 2 * N // 3:] = 0.                                   # u['c'] *= DA (:608-609)
         X = np.concatenate([transformInverse(snap[0], dom).ravel(), transformInverse(snap[1], dom).ravel()])
     return dom, [X * np.sqrt(E_0 / Inner_Prod_Discrete(X, X, dom))]
+
+
+# ---- "Continuous" formulation (the reference script's default Adjoint_type, :1728): FWD_Solve_Cnts :614, ADJ_Solve_Cnts :1161,
+# Inner_Prod_Cnts :264.  `domain` must be a PoiseuilleDomain(Nx, Nz, continuous=True); vectors live on its (3Nx/2, 3Nz/2) grid. --------------
+def _need_cnts(domain):
+    if not domain.continuous:
+        raise ValueError("the *_Cnts callables need a PoiseuilleDomain(..., continuous=True)")
+
+
+def FWD_Solve_Cnts(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-04, s=0, Prandtl=1., δ=0.25, filename=None):
+    """SBDF1 IVP on Nx x Nz modes (N_ITERS+1 steps like the script); cost -1/2 dt sum_{n=0}^{N} (1/V) integ |U_n|^2 (s = 0) or the mix-norm
+    of rho(T) (s = 1), integrals exact for the truncated series.  Snapshots: coefficients of u, w, b before every step."""
+    _need_cnts(domain)
+    ctx = domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ)
+    J = ctx.forward([_vec(U0)])
+    for k in ('u_fwd', 'w_fwd', 'b_fwd'):
+        X_FWD_DICT[k].ctx = ctx
+    return J
+
+
+def ADJ_Solve_Cnts(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-04, s=0, Prandtl=1., δ=0.25, Sim_Type="Non_Linear"):
+    """[u_adj, w_adj] after N_ITERS steps of the script's adjoint IVP on the 3/2 grid: an O(dt)-consistent approximation of dJ/dU0."""
+    _need_cnts(domain)
+    return domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ).adjoint(None, "Continuous")
+
+
+def Inner_Prod_Cnts(x, y, domain, rand_arg=None):
+    """(1/V) integ (x_u y_u + x_w y_w): grid product, truncated to the modes, integrated exactly (Integrate_Field :241-262)."""
+    _need_cnts(domain)
+    return domain.any_context().inner(x, y)
 
 
 Adjoint_type = "Discrete"

@@ -52,3 +52,6 @@ def test_poiseuille_script(in_tmp_cwd):
     R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "1", "--max-iters", "3", "--quiet"])
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
     assert len(X) == 1 and X[0].shape == (2 * 48 * 36,)
+    # the script's default formulation ("Continuous"): same grid, 32 x 24 modes; the cost must not increase either
+    R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "0", "--max-iters", "3", "--continuous", "--quiet"])
+    assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1)) and X[0].shape == (2 * 48 * 36,)

@@ -160,6 +160,31 @@ def test_poiseuille_transform_adjoints_and_taylor():
     assert abs(d - fd) < 2e-3 * abs(fd), (d, fd)
 
 
+def test_poiseuille_continuous_adjoint_is_first_order_consistent():
+    """The script's own adjoint PDE (ADJ_Solve_Cnts) approximates the gradient of the discrete cost to O(dt): the directional derivative
+    approaches the central difference as dt -> 0 (T fixed); the tau solve map equals the Discrete formulation's for the forward operator."""
+    from oracle.poiseuille import PoiseuilleCntsOracle, PoiseuilleOracle, solve_map_general, synthetic_ic_cnts
+    h = PoiseuilleOracle(24, 16, dt=5e-3)
+    assert np.abs(h.solve_map(3) - solve_map_general(h, 3, False)).max() < 1e-12
+    err = []
+    for n, dt in ((20, 1e-2), (80, 2.5e-3)):
+        o = PoiseuilleCntsOracle(16, 24, dt=dt, N_ITERS=n, s=0, delta=0.3)
+        X = synthetic_ic_cnts(o, 42); dX = synthetic_ic_cnts(o, 7)
+        assert abs(o.inner(X, X) - 0.02) < 1e-15
+        o.forward([X])
+        d = o.inner(o.adjoint([X])[0], dX)
+        fd = (o.forward([X + 1e-4 * dX]) - o.forward([X - 1e-4 * dX])) / 2e-4
+        err.append(abs(d - fd) / abs(fd))
+    assert err[0] < 0.1 and err[1] < 0.5 * err[0], err
+    # mix-norm cost: the gradient is second order in the amplitude, so test it where the flow actually stirs the stratification
+    o = PoiseuilleCntsOracle(16, 32, dt=5e-3, N_ITERS=40, s=1, delta=0.5)
+    X = 10. * synthetic_ic_cnts(o, 42); dX = synthetic_ic_cnts(o, 7)
+    o.forward([X])
+    d = o.inner(o.adjoint([X])[0], dX)
+    fd = (o.forward([X + 1e-2 * dX]) - o.forward([X - 1e-2 * dX])) / 2e-2
+    assert abs(d - fd) < 0.05 * abs(fd), (d, fd)
+
+
 def test_oracle_regression_poiseuille():
     from oracle.poiseuille import PoiseuilleOracle
     for sw in (0, 1):

@@ -99,3 +99,30 @@ def test_taylor_ic_and_errors():
     with pytest.raises(_capi.SmoError):
         pz.PoiseuilleDomain(50, 36).any_context()
     dom.drop_contexts()
+
+
+# ---- "Continuous" formulation (Dedalus IVPs of FWD_Solve_Cnts / ADJ_Solve_Cnts) --------------------------------------------------------------
+
+@pytest.mark.parametrize("Nx,Nz,n,s", [(16, 16, 6, 0), (16, 24, 10, 1), (32, 24, 12, 0), (64, 32, 5, 1)])
+def test_continuous_forward_adjoint_vs_oracle(Nx, Nz, n, s):
+    from oracle.poiseuille import PoiseuilleCntsOracle, synthetic_ic_cnts
+    o = PoiseuilleCntsOracle(Nx, Nz, dt=5e-3, N_ITERS=n, s=s, delta=0.3)
+    X = (10. if s == 1 else 1.) * synthetic_ic_cnts(o, 42)
+    dom = pz.PoiseuilleDomain(Nx, Nz, continuous=True)
+    buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+    args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.3]
+    J = pz.FWD_Solve_Cnts([X], *args)
+    g = pz.ADJ_Solve_Cnts([X], *args)
+    Jo = o.forward([X]); go = o.adjoint([X])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert len(g) == 1 and g[0].shape == X.shape and rel(g[0], go[0]) < RTOL, rel(g[0], go[0])
+    for f, key in enumerate(('u_fwd', 'w_fwd', 'b_fwd')):
+        for i in (0, 1, -1):
+            assert rel(buf[key][:, :, i], o.stack[f, :, :, i]) < 1e-8, (key, i)
+    ip = o.inner(X, go[0])
+    assert abs(pz.Inner_Prod_Cnts(X, g[0], dom) - ip) <= RTOL * abs(ip)
+    with pytest.raises(_capi.SmoError):
+        dom.context(*args[1:4], 5e-3, s, 1., 0.3).adjoint(None, "Discrete")
+    with pytest.raises(ValueError):
+        pz.FWD_Solve_Cnts([X], pz.PoiseuilleDomain(24, 24), *args[1:])
+    dom.drop_contexts()
