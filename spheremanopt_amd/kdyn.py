@@ -168,6 +168,9 @@ def FWD_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     J = ctx.forward([X0[0], X0[1]])
     for k in ('A_fwd', 'B_fwd', 'C_fwd'):
         X_FWD_DICT[k].ctx = ctx
+    if getattr(domain, "write_products", False):           # scalar_data/ and CheckPoints/ like the reference's file handlers
+        from . import products
+        products.write_kdyn(domain, ctx, X0, dt, N_ITERS, _coeff_to_grid_host)
     return J
 
 
@@ -176,6 +179,12 @@ def ADJ_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(Rm, dt, N_ITERS, Cost_function)
     return ctx.adjoint(None, Adjoint_type)
+
+
+def File_Manips(k):
+    """The reference's optimiser callback (FWD_Solve_KDyn.py:1006-1021): keep this iteration's scalar_data / CheckPoints files."""
+    from . import products
+    products.File_Manips(k)
 
 
 def Inner_Prod_3(x, y, domain, random_arg=None):

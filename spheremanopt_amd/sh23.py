@@ -118,7 +118,16 @@ def FWD_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filenam
     ctx = domain.context(dt, N_ITERS)
     J = ctx.forward([X_k[0]])
     X_FWD_DICT['A_fwd'].ctx = ctx
+    if getattr(domain, "write_products", False):           # scalar_data/ and CheckPoints/ like the reference's file handlers
+        from . import products
+        products.write_sh23(domain, ctx, dt, N_ITERS)
     return J
+
+
+def File_Manips(k):
+    """The reference's optimiser callback (FWD_Solve_SH23.py:731-746): keep this iteration's scalar_data / CheckPoints files."""
+    from . import products
+    products.File_Manips(k)
 
 
 def ADJ_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filename=None, Adjoint_type="Discrete"):

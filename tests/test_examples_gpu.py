@@ -55,3 +55,32 @@ def test_poiseuille_script(in_tmp_cwd):
     # the script's default formulation ("Continuous"): same grid, 32 x 24 modes; the cost must not increase either
     R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "0", "--max-iters", "3", "--continuous", "--quiet"])
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1)) and X[0].shape == (2 * 48 * 36,)
+
+
+def test_on_disk_products(in_tmp_cwd):
+    """write_products=True: scalar_data/ and CheckPoints/ with the groups the reference's plot scripts read; values against the snapshots."""
+    import os
+    from spheremanopt_amd import kdyn, products, sh23
+    dom, X = sh23.Generate_IC(0.0725, Npts=64)
+    dom.write_products = True
+    buf = sh23.GEN_BUFFER(dom, 40)
+    J = sh23.FWD_Solve_IVP_Lin([X], dom, 0.1, 40, 40, buf, None, "Discrete")
+    sd = products.read_products([f for f in (os.path.join("scalar_data", "scalar_data_s1.h5"), os.path.join("scalar_data", "scalar_data_s1.npz")) if os.path.exists(f)][0])
+    assert sd["tasks/Kinetic energy"].shape == (3, 1) and np.allclose(sd["scales/sim_time"], [0., 2., 4.])
+    assert abs(sd["tasks/Kinetic energy"][0, 0] - 0.0725) < 1e-12                     # <X,X> of the initial condition
+    cp = products.read_products([f for f in (os.path.join("CheckPoints", "CheckPoints_s1.h5"), os.path.join("CheckPoints", "CheckPoints_s1.npz")) if os.path.exists(f)][0])
+    assert cp["tasks/u"].shape == (2, 96) and cp["tasks/u_hat"].shape == (2, 32)
+    assert abs(np.mean(cp["tasks/u"][0] ** 2) - 0.0725) < 1e-12
+    sh23.File_Manips(0)
+    # KDyn, "Final" cost: the last sample of the magnetic energy is -J
+    domk, B, U = kdyn.Generate_IC(16, U_Noise=True)
+    domk.write_products = True
+    bufk = kdyn.GEN_BUFFER(16, domk, 20)
+    Jk = kdyn.FWD_Solve_IVP_Lin([B, U], domk, 1., 1e-2, 20, 20, bufk, "Final", "Discrete")
+    sd = products.read_products([f for f in (os.path.join("scalar_data", "scalar_data_s1.h5"), os.path.join("scalar_data", "scalar_data_s1.npz")) if os.path.exists(f)][0])
+    me = sd["tasks/Magnetic energy"]
+    assert me.shape == (2, 1, 1, 1) and abs(me[0, 0, 0, 0] - 1.0) < 1e-12 and abs(me[1, 0, 0, 0] + Jk) < 1e-12 * abs(Jk)
+    cp = products.read_products([f for f in (os.path.join("CheckPoints", "CheckPoints_s1.h5"), os.path.join("CheckPoints", "CheckPoints_s1.npz")) if os.path.exists(f)][0])
+    assert cp["tasks/A"].shape == (2, 24, 24, 24) and np.allclose(cp["tasks/A"][0].ravel(), B[:24 ** 3], atol=1e-12)
+    kdyn.File_Manips(1)
+    assert any(f.startswith("CheckPoints_iter_1") for f in os.listdir("."))

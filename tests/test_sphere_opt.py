@@ -146,3 +146,19 @@ def test_result_record_format():
     s = str(R)
     assert s.startswith("Optimize_rotation succeed \n")
     assert "Residual error r_k   = [0.5, 0.25]\n" in s and s.endswith("J(X_opt)             = 3.0\n")
+
+
+def test_products_files_round_trip(in_tmp_cwd):
+    """scalar_data / CheckPoints writers (HDF5 paths as keys; .npz when h5py is absent) and the File_Manips callback."""
+    import os
+    from spheremanopt_amd import products
+    g = {"tasks/Kinetic energy": np.arange(6.).reshape(6, 1), "scales/sim_time": 0.1 * np.arange(6), "scales/x/1.5": np.linspace(0, 1, 4)}
+    f = products.write_products(os.path.join("scalar_data", "scalar_data_s1"), g)
+    products.write_products(os.path.join("CheckPoints", "CheckPoints_s1"), {"tasks/u": np.ones((2, 4))})
+    back = products.read_products(f)
+    assert set(back) == set(g) and all(np.array_equal(back[k], g[k]) for k in g)
+    products.File_Manips(3)
+    ext = os.path.splitext(f)[1]
+    assert os.path.exists("scalar_data_iter_3" + ext) and os.path.exists("CheckPoints_iter_3" + ext)
+    assert np.array_equal(products.read_products("CheckPoints_iter_3" + ext)["tasks/u"], np.ones((2, 4)))
+    assert list(products.sample_iterations(45)) == [0, 20, 40]
