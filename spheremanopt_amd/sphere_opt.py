@@ -14,7 +14,6 @@ so that ``tests/golden/pca_*.npz`` (traces captured from the reference on the PC
 example) are matched bit for bit.  The public names and signatures are the reference's.
 """
 import copy
-import math
 from warnings import warn
 
 import numpy as np

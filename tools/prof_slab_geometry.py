@@ -6,7 +6,6 @@ import json
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
