@@ -126,3 +126,31 @@ def test_continuous_forward_adjoint_vs_oracle(Nx, Nz, n, s):
     with pytest.raises(ValueError):
         pz.FWD_Solve_Cnts([X], pz.PoiseuilleDomain(24, 24), *args[1:])
     dom.drop_contexts()
+
+
+def test_reference_resolution_properties():
+    """384 x 192 (the reference script's 3/2 * (256, 128)), 100 steps: size-independent checks — Taylor test of the exact discrete
+    gradient (kinetic-energy cost), boundary conditions and incompressibility of the last snapshot, de-aliased snapshots."""
+    Nx, Nz, n = 384, 192, 100
+    dom, U0 = pz.Generate_IC(Nx, Nz, E_0=0.02, seed=42)
+    _, dU0 = pz.Generate_IC(Nx, Nz, E_0=0.02, seed=7)
+    buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+    args_f = [dom, 500., 0.05, n, buf, 5e-3, 0, 1., 0.125]
+    AA = taylor_table(U0, dU0, pz.FWD_Solve, pz.ADJ_Solve, pz.Inner_Prod, args_f, [dom, None], epsilon=1e-3)
+    assert np.all(np.abs(AA[4, :4] - 2.0) < 2e-2), AA
+    u, w = buf['u_fwd'][:, :, -1], buf['w_fwd'][:, :, -1]
+    sg = (-1.) ** np.arange(Nz)
+    scale = np.abs(u).max()
+    assert np.abs(u.sum(axis=1)).max() < 1e-10 * scale and np.abs((u * sg).sum(axis=1)).max() < 1e-10 * scale       # u(+-1) = 0
+    assert np.abs(w.sum(axis=1)).max() < 1e-10 * scale and np.abs((w * sg).sum(axis=1)).max() < 1e-10 * scale       # w(+-1) = 0
+    assert np.abs(u[dom.ada:]).max() == 0.0 and np.abs(buf['b_fwd'][1:, :, 0]).max() == 0.0                         # de-aliased in x; rho_0 = rho_0(z)
+    # continuity of the tau solution: i k u + wz = 0 with wz = Dz w up to the tau term in the highest mode
+    k = 2. * np.pi * np.arange(dom.a) / (4. * np.pi)
+    D = np.zeros((Nz, Nz))
+    for i in range(Nz):
+        for j in range(i + 1, Nz):
+            D[i, j] = 2. * j * ((j - i) % 2)
+    D[0] /= 2.
+    div = 1j * k[:, None] * u + w @ D.T
+    assert np.abs(div[:, :Nz - 2]).max() < 1e-6 * np.abs(w @ D.T).max()
+    dom.drop_contexts()
