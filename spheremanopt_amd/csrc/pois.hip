@@ -103,15 +103,22 @@ __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ de
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S, const double* __restrict__ in, const double* __restrict__ xin_v,
                                                   double* __restrict__ out, double* __restrict__ xout_v, double* __restrict__ snap, int a, int modes,
-                                                  int Nz, int nin, int xin, int nout, int xout) {
+                                                  int Nz, int nin, int xin, int nout, int xout, int structure) {
     const int lane = threadIdx.x & 63;
     const int rows = nout * Nz + xout, cols = nin * Nz + xin, fcols = nin * Nz;
     const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gr >= (long long)modes * rows) return;
     const int n = (int)(gr / rows), r = (int)(gr - (long long)n * rows);
     const double2* Srow = S + ((size_t)n * rows + r) * cols;
+    // structural zeros of the tau operator: the density block is decoupled from the velocity right-hand sides.  structure 1 (forward
+    // operator): density rows (field 2 and extra 2) only see the density columns; structure 2 (its conjugate transpose): the velocity
+    // rows do not see the density columns (field 2, extra 2).  The skipped entries are exact zeros: not read, not multiplied.
+    int c_lo = 0, skip_lo = cols, skip_hi = cols, skip_x = -1;
+    if (structure == 1 && ((r < nout * Nz) ? (r / Nz == 2) : (r - nout * Nz == 2))) c_lo = 2 * Nz;
+    if (structure == 2 && r < 2 * Nz) { skip_lo = 2 * Nz; skip_hi = 3 * Nz; skip_x = fcols + 2; }
     double yr = 0.0, yi = 0.0;
-    for (int c = lane; c < cols; c += 64) {
+    for (int c = c_lo + lane; c < cols; c += 64) {
+        if ((c >= skip_lo && c < skip_hi) || c == skip_x) continue;
         double xr, xi;
         if (c < fcols) {
             const int fi = c / Nz, j = c - fi * Nz;
@@ -445,11 +452,11 @@ public:
     }
     // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
     int apply(const double2* S, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int nin, int xin, int nout,
-              int xout, int modes) {
+              int xout, int modes, int structure = 0) {
         const long long rows = (long long)modes * (nout * Nz + xout);
         ScopedTimer t(timing, k_apply, stream);
         hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, xin_v, out, xout_v, snap, a, modes, Nz, nin, xin,
-                           nout, xout);
+                           nout, xout, structure);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
@@ -669,7 +676,7 @@ public:
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, S6, 1.0 / cfg.dt, HC, 3 * nC);
             }
-            SMO_TRY(apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada));
+            SMO_TRY(apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada, 1));
             SMO_TRY(run(F1d));                                               // uz, vz, rhoz = (u, v, rho) Dz^T + last coefficient * q
             {
                 ScopedTimer t(timing, k_point, stream);
@@ -747,7 +754,7 @@ public:
                 hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
                 hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, L6, 1.0, HC, 3 * nC);
             }
-            SMO_TRY(apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a));
+            SMO_TRY(apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2));
             SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
             SMO_TRY(run(Az)); SMO_TRY(run(Ax));
             {
@@ -901,7 +908,7 @@ public:
         const long long rows = (long long)a * (nout * Nz + xo);
         ScopedTimer t(timing, k_apply, stream);
         hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, (const double*)nullptr, out, xout, (double*)nullptr, a,
-                           a, Nz, nin, 0, nout, xo);
+                           a, Nz, nin, 0, nout, xo, 0);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
