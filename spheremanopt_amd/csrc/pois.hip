@@ -557,7 +557,7 @@ public:
             std::vector<cd> S((size_t)a * sz), SH((size_t)a * sz), SM((size_t)a * szm), SMH((size_t)a * szm);
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
-            const int nthr = std::max(1, std::min<int>(a, (int)std::thread::hardware_concurrency()));
+            const int nthr = std::max(1, std::min<int>(std::min(a, 32), (int)std::thread::hardware_concurrency()));   // one wavenumber per task; <= 32 host threads
             auto work = [&](int t) {
                 for (int n = t; n < a; n += nthr) {
                     std::vector<cd> s, sm;
@@ -987,7 +987,7 @@ public:
             std::vector<cd> S((size_t)a * sz), SA((size_t)a * sz), SM((size_t)a * szm);
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
-            const int nthr = std::max(1, std::min<int>(a, (int)std::thread::hardware_concurrency()));
+            const int nthr = std::max(1, std::min<int>(std::min(a, 32), (int)std::thread::hardware_concurrency()));   // one wavenumber per task; <= 32 host threads
             auto reduce = [&](const std::vector<cd>& s, cd* dst) {
                 std::copy(s.begin(), s.begin() + (size_t)3 * N * 3 * N, dst);
                 for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * 3 * N], &s[((size_t)(3 + f) * N + N - 1) * 3 * N] + 3 * N, dst + (size_t)(3 * N + f) * 3 * N);
