@@ -67,3 +67,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_struct(tmp_path):
+    """include/smo.h compiles as C99 and as C++; sizeof / field offsets of smo_config equal the ctypes mirror in _capi.py
+    (and therefore the stub printed in INTEGRATION.md, which lists the same fields)."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    fields = [f[0] for f in _capi.smo_config._fields_]
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "smo.h"\nint main(void){ printf("%zu", sizeof(smo_config));\n' +
+                   "".join('printf(" %%zu", offsetof(smo_config, %s));\n' % f for f in fields) + "return 0; }\n")
+    inc = os.path.join(ROOT, "include")
+    exe = str(tmp_path / "abi")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", exe], check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)], check=True)
+    vals = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_capi.smo_config)
+    assert vals[1:] == [getattr(_capi.smo_config, f).offset for f in fields]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for f in fields:
+        assert '("%s"' % f in doc, f
