@@ -151,6 +151,26 @@ def Generate_IC(Npts, X=(0., 2. * np.pi), M_0=1.0, U_Noise=False, seeds=(1, 2), 
     return dom, B, U
 
 
+def Vec_to_Field(domain, X):
+    """The reference splits the flat vector into three Dedalus fields on the 3/2 grid (FWD_Solve_KDyn.py:139-171).  Here the flat vector
+    IS the layout the device kernels read ([3][G][G][G], z fastest): this returns the three (G,G,G) component arrays (views)."""
+    x = np.asarray(X, dtype=np.float64).reshape(-1)
+    if x.size != 3 * domain.G ** 3:
+        raise ValueError("vector has %d entries, three fields on the grid have %d" % (x.size, 3 * domain.G ** 3))
+    a, b, c = x.reshape(3, domain.G, domain.G, domain.G)
+    return a, b, c
+
+
+def Field_to_Vec(domain, Fx, Fy, Fz):
+    """Inverse of Vec_to_Field (FWD_Solve_KDyn.py:91-137: gather + allgather): the three grid arrays concatenated."""
+    return np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1) for f in (Fx, Fy, Fz)])
+
+
+def Integrate_Field(domain, F):
+    """(1/V) integ F dV of a field on the 3/2 grid = its grid mean (FWD_Solve_KDyn.py:68-89)."""
+    return float(np.mean(np.asarray(F, dtype=np.float64)))
+
+
 def GEN_BUFFER(Npts, domain, N_SUB_ITERS):
     shape = (domain.a, domain.m, domain.m, N_SUB_ITERS + 1)
     return {'A_fwd': SnapshotStack(0, shape), 'B_fwd': SnapshotStack(1, shape), 'C_fwd': SnapshotStack(2, shape)}

@@ -76,6 +76,21 @@ class PoiseuilleDomain:
         self._ctx = {}
 
 
+def Vec_to_Field(domain, U0):
+    """Flat vector -> the (u, w) grid arrays, each (gx, gz) with z fastest (FWD_Solve_Poiseuille.py:209-239); views, no copy."""
+    gx, gz = domain.gshape
+    x = np.asarray(_vec(U0), dtype=np.float64).reshape(-1)
+    if x.size != 2 * gx * gz:
+        raise ValueError("vector has %d entries, two fields on the grid have %d" % (x.size, 2 * gx * gz))
+    u, w = x.reshape(2, gx, gz)
+    return u, w
+
+
+def Field_to_Vec(domain, Fx, Fz):
+    """Inverse of Vec_to_Field (FWD_Solve_Poiseuille.py:160-207)."""
+    return np.concatenate([np.asarray(Fx, dtype=np.float64).reshape(-1), np.asarray(Fz, dtype=np.float64).reshape(-1)])
+
+
 def GEN_BUFFER(Nx, Nz, domain, N_ITERS):
     shape = (domain.a, domain.Nz, N_ITERS + 1)
     return {'u_fwd': SnapshotStack(shape, 0), 'w_fwd': SnapshotStack(shape, 1), 'b_fwd': SnapshotStack(shape, 2)}

@@ -103,6 +103,25 @@ def Generate_IC(E_0=1.0, Npts=256, X=(0., 12. * np.pi), seed=42, device=0, prep=
     return dom, x
 
 
+def Vec_to_Field(domain, X):
+    """The reference scatters the flat vector into a Dedalus field on the scale-2 grid (FWD_Solve_SH23.py:130-156).  Here the flat
+    vector IS the grid layout the device kernels read: this returns it as the (G,) grid array (a view, no copy, no MPI scatter)."""
+    x = np.asarray(X, dtype=np.float64).reshape(-1)
+    if x.size != domain.G:
+        raise ValueError("vector has %d entries, the scale-2 grid has %d" % (x.size, domain.G))
+    return x
+
+
+def Field_to_Vec(domain, F):
+    """Inverse of Vec_to_Field (FWD_Solve_SH23.py:89-128: gather + allgather): the grid array is the flat vector."""
+    return np.ascontiguousarray(F, dtype=np.float64).reshape(-1)
+
+
+def Integrate_Field(domain, F):
+    """(1/L) integ F dx of a field given on the scale-2 grid = its grid mean (FWD_Solve_SH23.py:66-87)."""
+    return float(np.mean(np.asarray(F, dtype=np.float64)))
+
+
 def GEN_BUFFER(domain, N_SUB_ITERS, Npts=256):
     return {'A_fwd': SnapshotStack((domain.Nc, N_SUB_ITERS + 1))}
 

@@ -94,6 +94,19 @@ def transformInverseAdjoint(x, domain=None):
     return _transform(3, x, domain)
 
 
+def Vec_to_Field(domain, X):
+    """Flat vector -> values on the ascending Gauss-Chebyshev grid (FWD_Solve_SHB23.py:128-154); the same array here (a view)."""
+    x = np.asarray(X, dtype=np.float64).reshape(-1)
+    if x.size != domain.G:
+        raise ValueError("vector has %d entries, the grid has %d" % (x.size, domain.G))
+    return x
+
+
+def Field_to_Vec(domain, F):
+    """Inverse of Vec_to_Field (FWD_Solve_SHB23.py:87-126)."""
+    return np.ascontiguousarray(F, dtype=np.float64).reshape(-1)
+
+
 def GEN_BUFFER(Npts, domain, N_SUB_ITERS):
     """Grid states (Discrete) or T-coefficients (Continuous) of every step: shape (Npts, N_SUB_ITERS+1) either way (SHB:298-312)."""
     return {'A_fwd': SnapshotStack((domain.Npts, N_SUB_ITERS + 1))}

@@ -162,3 +162,25 @@ def test_products_files_round_trip(in_tmp_cwd):
     assert os.path.exists("scalar_data_iter_3" + ext) and os.path.exists("CheckPoints_iter_3" + ext)
     assert np.array_equal(products.read_products("CheckPoints_iter_3" + ext)["tasks/u"], np.ones((2, 4)))
     assert list(products.sample_iterations(45)) == [0, 20, 40]
+
+
+def test_vec_field_helpers_are_views_of_the_flat_layout():
+    """Vec_to_Field / Field_to_Vec of every problem module: the reference's flat-vector layouts, no device needed."""
+    from spheremanopt_amd import kdyn, poiseuille, sh23, shb23
+    d = sh23.SH23Domain(16)
+    x = np.arange(32.)
+    assert np.shares_memory(sh23.Vec_to_Field(d, x), x) and np.array_equal(sh23.Field_to_Vec(d, sh23.Vec_to_Field(d, x)), x)
+    assert sh23.Integrate_Field(d, x) == np.mean(x)
+    k = kdyn.KDynDomain(8)
+    v = np.arange(3. * 12 ** 3)
+    a, b, c = kdyn.Vec_to_Field(k, v)
+    assert a.shape == (12, 12, 12) and np.shares_memory(b, v) and c[0, 0, 1] == 2 * 12 ** 3 + 1      # component-major, z fastest
+    assert np.array_equal(kdyn.Field_to_Vec(k, a, b, c), v)
+    s = shb23.SHBDomain(64)
+    assert np.array_equal(shb23.Field_to_Vec(s, shb23.Vec_to_Field(s, np.arange(64.))), np.arange(64.))
+    p = poiseuille.PoiseuilleDomain(24, 12)
+    w = np.arange(2. * 24 * 12)
+    u, ww = poiseuille.Vec_to_Field(p, [w])
+    assert u.shape == (24, 12) and ww[0, 1] == 24 * 12 + 1 and np.array_equal(poiseuille.Field_to_Vec(p, u, ww), w)
+    with pytest.raises(ValueError):
+        kdyn.Vec_to_Field(k, v[:-1])
