@@ -107,7 +107,16 @@ def FWD_Solve_Discrete(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt
     J = ctx.forward([_vec(U0)])
     for k in ('u_fwd', 'w_fwd', 'b_fwd'):
         X_FWD_DICT[k].ctx = ctx
+    if getattr(domain, "write_products", False):           # scalar_data_s1 / CheckPoints_s1 like the reference (:945-1151)
+        from . import products
+        products.write_poiseuille(domain, ctx, dt, N_ITERS, s)
     return J
+
+
+def File_Manips(k):
+    """The reference's optimiser callback (FWD_Solve_Poiseuille.py:1698-1741): keep this iteration's scalar_data / CheckPoints files."""
+    from . import products
+    products.File_Manips(k)
 
 
 def ADJ_Solve_Discrete(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-04, s=0, Prandtl=1., δ=0.25, Sim_Type="Non_Linear"):

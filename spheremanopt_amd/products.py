@@ -43,9 +43,11 @@ def read_products(path):
 
 
 def File_Manips(k):
-    """Keep the products of optimiser iteration k: scalar_data_iter_k / CheckPoints_iter_k next to DAL_PROGRESS (reference callback)."""
+    """Keep the products of optimiser iteration k: scalar_data_iter_k / CheckPoints_iter_k next to DAL_PROGRESS (reference callback).
+    The Dedalus file handlers write into sub-directories, the hand-stepped Discrete solvers into the working directory
+    (FWD_Solve_SHB23.py:931-946 handles both the same way)."""
     for stem in ("scalar_data", "CheckPoints"):
-        for src in glob.glob(os.path.join(stem, stem + "_s1.*")):
+        for src in glob.glob(os.path.join(stem, stem + "_s1.*")) + glob.glob(stem + "_s1.*"):
             shutil.copyfile(src, "%s_iter_%i%s" % (stem, k, os.path.splitext(src)[1]))
 
 
@@ -105,4 +107,55 @@ def write_kdyn(domain, ctx, X0, dt, N_ITERS, coeff_to_grid):
     for name, comp in (("u-velocity", 0), ("v-velocity", 1), ("w-velocity", 2)):
         groups["tasks/" + name] = np.stack([U[comp], U[comp]])
     f2 = write_products(os.path.join("CheckPoints", "CheckPoints_s1"), groups)
+    return f1, f2
+
+
+# ---- SHB23 (Discrete): files in the working directory, every step (FWD_Solve_SHB23.py:604-672) ---------------------------------------
+def write_shb23(domain, ctx, dt, N_ITERS, W):
+    """'Kinetic energy' = <u_i,u_i>_W for i = 0..N-1; CheckPoints: u on the Gauss grid at i = 0 and i = N-1."""
+    Lz = domain.interval[1] - domain.interval[0]
+    ke = np.array([float(np.dot(u, W * u) / Lz) for u in (ctx.snapshot(i) for i in range(N_ITERS))])
+    f1 = write_products("scalar_data_s1", {"tasks/Kinetic energy": ke, "scales/sim_time": dt * np.arange(N_ITERS)})
+    f2 = write_products("CheckPoints_s1", {"tasks/u": np.stack([ctx.snapshot(0), ctx.snapshot(N_ITERS - 1)]), "scales/z/1.5": domain.grid()})
+    return f1, f2
+
+
+# ---- Poiseuille (Discrete): files in the working directory (FWD_Solve_Poiseuille.py:945-1151) ----------------------------------------
+def write_poiseuille(domain, ctx, dt, N_ITERS, s):
+    """'Kinetic  energy' (two spaces, as in the reference) and 'Buoyancy energy' with the discrete inner product, for i = 0..N-1 and,
+    when s = 0, the final state; CheckPoints: vorticity, b, u, w on the (Nx, Nz) grid at i = 0 and i = N-1."""
+    Nx, Nz, a = domain.Nx, domain.Nz, domain.a
+    Lx = domain.interval[1] - domain.interval[0]
+    z = domain.grid(1)
+    dz = np.empty(Nz); dz[0] = z[1] - z[0]; dz[1:] = z[1:] - z[:-1]
+    W, V = dz * (Lx / Nx), domain.hypervolume
+    j, i = np.arange(Nz)[None, :], np.arange(Nz)[:, None]
+    Ti = np.cos(np.pi * j * (2 * i + 1) / (2. * Nz)) * (-1.) ** j                   # T coefficients -> Gauss grid (POIS:67-76)
+    D = np.zeros((Nz, Nz))
+    for r in range(Nz):
+        for c in range(r + 1, Nz):
+            D[r, c] = 2. * c * ((c - r) % 2)
+    D[0] /= 2.
+    k = 2. * np.pi * np.arange(a) / Lx
+
+    def grid(c):                                                                     # (a, Nz) coefficients -> (Nx, Nz) grid
+        F = np.zeros((Nx // 2 + 1, Nz), dtype=complex)
+        F[:a] = c @ Ti.T
+        F[0] = F[0].real
+        return np.fft.irfft(F, n=Nx, axis=0) * Nx
+
+    last = N_ITERS + 1 if s == 0 else N_ITERS                                       # with s = 1 the last slot holds the mix-norm fields
+    ke, de, saved = np.empty(last), np.empty(last), {}
+    for n in range(last):
+        c = ctx.snapshot(n).view(np.complex128).reshape(3, a, Nz)
+        u, w, b = grid(c[0]), grid(c[1]), grid(c[2])
+        ke[n] = np.sum(W * (u * u + w * w)) / V
+        de[n] = np.sum(W * b * b) / V
+        if n in (0, N_ITERS - 1):
+            saved[n] = (grid(1j * k[:, None] * c[1]) - grid(c[0] @ D.T), b, u, w)
+    f1 = write_products("scalar_data_s1", {"tasks/Kinetic  energy": ke, "tasks/Buoyancy energy": de, "scales/sim_time": dt * np.arange(last)})
+    keys = ("vorticity", "b", "u", "w")
+    groups = {"tasks/" + name: np.stack([saved[0][q], saved[N_ITERS - 1][q]]) for q, name in enumerate(keys)}
+    groups.update({"scales/x/1.5": domain.grid(0), "scales/z/1.5": z})
+    f2 = write_products("CheckPoints_s1", groups)
     return f1, f2

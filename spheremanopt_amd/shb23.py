@@ -131,7 +131,16 @@ def FWD_Solve_IVP_Discrete(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=
     ctx = domain.context(dt, N_ITERS)
     J = ctx.forward([X_k[0]])
     X_FWD_DICT['A_fwd'].ctx = ctx
+    if getattr(domain, "write_products", False) and domain.dealias == 1:      # scalar_data_s1 / CheckPoints_s1 like the reference (:604-672)
+        from . import products
+        products.write_shb23(domain, ctx, dt, N_ITERS, weightMatrixDisc(domain))
     return J
+
+
+def File_Manips(k):
+    """The reference's optimiser callback (FWD_Solve_SHB23.py:923-948): keep this iteration's scalar_data / CheckPoints files."""
+    from . import products
+    products.File_Manips(k)
 
 
 def ADJ_Solve_IVP_Discrete(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=None):

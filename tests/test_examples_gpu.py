@@ -1,4 +1,6 @@
 """The reference's example scripts (its `__main__` blocks) on the device path: same call sequence, reduced lengths."""
+import os
+
 import numpy as np
 import pytest
 
@@ -84,3 +86,33 @@ def test_on_disk_products(in_tmp_cwd):
     assert cp["tasks/A"].shape == (2, 24, 24, 24) and np.allclose(cp["tasks/A"][0].ravel(), B[:24 ** 3], atol=1e-12)
     kdyn.File_Manips(1)
     assert any(f.startswith("CheckPoints_iter_1") for f in os.listdir("."))
+
+
+def test_on_disk_products_of_the_hand_stepped_solvers(in_tmp_cwd):
+    """SHB23 / Poiseuille (Discrete) write scalar_data_s1 and CheckPoints_s1 into the working directory, every step, like the reference."""
+    import glob
+    from spheremanopt_amd import poiseuille as pz, products, shb23
+    dom, X = shb23.Generate_IC(64, M_0=0.0019)
+    dom.write_products = True
+    buf = shb23.GEN_BUFFER(64, dom, 20)
+    J = shb23.FWD_Solve([X], dom, buf, 20)
+    sd = products.read_products(glob.glob("scalar_data_s1.*")[0])
+    ke = sd["tasks/Kinetic energy"]
+    assert ke.shape == (20,) and abs(ke[0] - 0.0019) < 1e-14 and np.allclose(sd["scales/sim_time"], 1e-2 * np.arange(20))
+    last = shb23.Inner_Prod(buf['A_fwd'][:, 20], buf['A_fwd'][:, 20], dom)
+    assert abs(-J - 1e-2 * (ke.sum() + last)) < 1e-12 * abs(J)                        # J = dt * sum_{n=0}^{N} <u_n,u_n>
+    cp = products.read_products(glob.glob("CheckPoints_s1.*")[0])
+    assert cp["tasks/u"].shape == (2, 64) and np.allclose(cp["tasks/u"][0], X, atol=1e-13)
+    shb23.File_Manips(2)
+    assert glob.glob("scalar_data_iter_2.*") and glob.glob("CheckPoints_iter_2.*")
+    for f in glob.glob("*_s1.*"):
+        os.remove(f)
+    domp, U0 = pz.Generate_IC(48, 36, E_0=0.02)
+    domp.write_products = True
+    bufp = pz.GEN_BUFFER(48, 36, domp, 12)
+    Jp = pz.FWD_Solve(U0, domp, 500., 0.05, 12, bufp, 5e-3, 0, 1., 0.3)
+    sd = products.read_products(glob.glob("scalar_data_s1.*")[0])
+    ke = sd["tasks/Kinetic  energy"]
+    assert ke.shape == (13,) and abs(ke[0] - 0.02) < 1e-10 and abs(Jp + 0.5 * 5e-3 * ke.sum()) < 1e-10 * abs(Jp)
+    cp = products.read_products(glob.glob("CheckPoints_s1.*")[0])
+    assert cp["tasks/vorticity"].shape == (2, 48, 36) and np.allclose(cp["tasks/u"][0].ravel(), U0[0][:48 * 36], atol=1e-10)
