@@ -104,6 +104,25 @@ def test_size_independent_properties():
     dom.drop_contexts()
 
 
+def test_known_answer_single_mode_decay():
+    """U = 0, B = (0, cos 3x, 0): every CNAB1 step multiplies the mode by (1/dt - 9/2Rm)/(1/dt + 9/2Rm) — an answer that does not
+    come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost."""
+    N, n, dt, Rm = 32, 9, 1e-2, 1.3
+    dom = kdyn.KDynDomain(N)
+    G = dom.G
+    x = 2. * np.pi * np.arange(G) / G
+    B = np.zeros((3, G, G, G)); B[1] = np.cos(3. * x)[:, None, None]
+    B = B.reshape(-1); U = np.zeros(3 * G ** 3)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, Rm, dt, n, n, buf, "Final", "Discrete"]
+    r = (1. / dt - 9. / (2. * Rm)) / (1. / dt + 9. / (2. * Rm))
+    J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    assert abs(J + 0.5 * r ** (2 * n)) < 1e-13
+    gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    assert np.abs(gB + 2. * r ** (2 * n) * B).max() < 1e-12 and np.abs(gU).max() < 1e-12
+    dom.drop_contexts()
+
+
 def test_errors():
     with pytest.raises(_capi.SmoError):
         _capi.Context(_capi.SMO_KDYN, 20, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size

@@ -196,6 +196,30 @@ def test_oracle_regression_poiseuille():
         assert np.linalg.norm(grad - g["grad"]) <= 1e-9 * np.linalg.norm(g["grad"])
 
 
+def test_known_answers_of_the_time_steppers():
+    """Closed-form checks that do not involve any restated Dedalus internals beyond the published schemes:
+    KDyn with U = 0: a single solenoidal Fourier mode is multiplied per CNAB1 step by (1/dt - k^2/2Rm) / (1/dt + k^2/2Rm);
+    SH23 at infinitesimal amplitude: mode k is multiplied per SBDF1 step by (1/dt) / (1/dt + (1-k^2)^2 - a)."""
+    N, n, dt, Rm = 16, 7, 1e-2, 1.3
+    k = KDynOracle(N, Rm=Rm, dt=dt, N_ITERS=n)
+    G = k.G
+    x = 2. * np.pi * np.arange(G) / G
+    B = np.zeros((3, G, G, G)); B[1] = np.cos(3. * x)[:, None, None]                  # B = (0, cos 3x, 0): k.B = 0, |k|^2 = 9
+    U = np.zeros(3 * G ** 3)
+    r = (1. / dt - 9. / (2. * Rm)) / (1. / dt + 9. / (2. * Rm))
+    J = k.forward([B.reshape(-1), U])
+    assert abs(J + 0.5 * r ** (2 * n)) < 1e-13                                        # <B0,B0> = 1/2
+    o = SH23Oracle(64, dt=0.1, N_ITERS=20)
+    xs = o.L * np.arange(o.G) / o.G
+    eps, m = 1e-9, 5                                                                  # mode 5 of the 12 pi box: k = 5/6
+    X = eps * np.cos(2. * np.pi * m * xs / o.L)
+    km = 2. * np.pi * m / o.L
+    rs = (1. / 0.1) / (1. / 0.1 + (1. - km ** 2) ** 2 + 0.3)
+    Jo = o.forward([X])
+    expect = -0.1 * 0.5 * eps ** 2 * sum(rs ** (2 * i) for i in range(21))
+    assert abs(Jo - expect) < 1e-7 * abs(expect)
+
+
 def test_kdyn_invariants():
     k = KDynOracle(12, Rm=1., dt=1e-2, N_ITERS=5)
     B = synthetic_field(k.G, 1); U = synthetic_field(k.G, 2)

@@ -70,6 +70,22 @@ def test_taylor_remainder_on_device_path():
     assert np.all(np.abs(AA[3, :4] - 1.0) < 5e-2), AA
 
 
+def test_known_answer_linear_growth():
+    """Infinitesimal amplitude: mode k is multiplied per SBDF1 step by (1/dt)/(1/dt + (1-k^2)^2 - a) — not taken from the oracle."""
+    dom = sh23.SH23Domain(64)
+    xs = dom.grid()
+    L = dom.hypervolume
+    eps, m, dt, n = 1e-9, 5, 0.1, 20
+    X = eps * np.cos(2. * np.pi * m * xs / L)
+    km = 2. * np.pi * m / L
+    r = (1. / dt) / (1. / dt + (1. - km ** 2) ** 2 + 0.3)
+    buf = sh23.GEN_BUFFER(dom, n)
+    J = sh23.FWD_Solve_IVP_Lin([X], dom, dt, n, n, buf, None, "Discrete")
+    expect = -dt * 0.5 * eps ** 2 * sum(r ** (2 * i) for i in range(n + 1))
+    assert abs(J - expect) < 1e-7 * abs(expect)
+    assert abs(abs(buf['A_fwd'][m, n]) - 0.5 * eps * r ** n) < 1e-7 * eps
+
+
 def test_batched_problems_are_independent():
     Npts, dt, n, B = 64, 0.1, 30, 5
     dom = sh23.SH23Domain(Npts)
