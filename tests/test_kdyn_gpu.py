@@ -120,6 +120,13 @@ def test_known_answer_single_mode_decay():
     assert abs(J + 0.5 * r ** (2 * n)) < 1e-13
     gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
     assert np.abs(gB + 2. * r ** (2 * n) * B).max() < 1e-12 and np.abs(gU).max() < 1e-12
+    # uniform flow U = (c,0,0): explicit advection => |factor|^2 = ((1/dt - D/2)^2 + 9 c^2) / (1/dt + D/2)^2 per step (exercises the
+    # grid cross product, the curl and the projection against a closed form)
+    c = 0.7
+    Uc = np.zeros((3, G, G, G)); Uc[0] = c
+    J = kdyn.FWD_Solve_IVP_Lin([B, Uc.reshape(-1)], *args)
+    r2 = ((1. / dt - 9. / (2. * Rm)) ** 2 + 9. * c * c) / (1. / dt + 9. / (2. * Rm)) ** 2
+    assert abs(J + 0.5 * r2 ** n) < 1e-13
     dom.drop_contexts()
 
 

@@ -209,6 +209,12 @@ def test_known_answers_of_the_time_steppers():
     r = (1. / dt - 9. / (2. * Rm)) / (1. / dt + 9. / (2. * Rm))
     J = k.forward([B.reshape(-1), U])
     assert abs(J + 0.5 * r ** (2 * n)) < 1e-13                                        # <B0,B0> = 1/2
+    # uniform flow U = (c,0,0): curl(U x B) = -c dB/dx is treated explicitly => factor [(1/dt - D/2) - 3ic] / (1/dt + D/2), D = 9/Rm
+    c = 0.7
+    Uc = np.zeros((3, G, G, G)); Uc[0] = c
+    J = k.forward([B.reshape(-1), Uc.reshape(-1)])
+    r2 = ((1. / dt - 9. / (2. * Rm)) ** 2 + 9. * c * c) / (1. / dt + 9. / (2. * Rm)) ** 2
+    assert abs(J + 0.5 * r2 ** n) < 1e-13
     o = SH23Oracle(64, dt=0.1, N_ITERS=20)
     xs = o.L * np.arange(o.G) / o.G
     eps, m = 1e-9, 5                                                                  # mode 5 of the 12 pi box: k = 5/6
