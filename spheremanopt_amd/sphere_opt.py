@@ -384,6 +384,24 @@ def _dump_progress(R):
         pass
 
 
+def load_progress(path=None):
+    """Read a progress record back (the manual restart of the reference scripts, FWD_Solve_SH23.py:787-800: `X_0 = DAL_file['X_opt']`):
+    returns a dict of every field written by the optimiser ('X_opt', 'fun', 'nit', ...).  path: DAL_PROGRESS.h5 / .npz (default: whichever
+    exists in the working directory, HDF5 first)."""
+    import os
+    if path is None:
+        path = next((p for p in ('DAL_PROGRESS.h5', 'DAL_PROGRESS.npz') if os.path.exists(p)), None)
+        if path is None:
+            raise FileNotFoundError("no DAL_PROGRESS.h5 / DAL_PROGRESS.npz in %s" % os.getcwd())
+    if path.endswith('.npz'):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    if _h5py is None:
+        raise RuntimeError("reading %s needs h5py" % path)
+    with _h5py.File(path, 'r') as fh:
+        return {k: fh[k][()] for k in fh.keys()}
+
+
 def Optimise_On_Multi_Sphere(X_0, M_0, f, myfprime, inner_prod, args_f=(), args_IP=(), kwargs_f={},
                              kwargs_IP={}, err_tol=1e-06, max_iters=200, alpha_k=1., LS='LS_wolfe',
                              CG=True, callback=None, verbose=True):

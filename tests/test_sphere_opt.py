@@ -52,6 +52,8 @@ def test_pca_traces_match_reference(DIM, in_tmp_cwd):
         prog = np.load("DAL_PROGRESS.npz")
         assert int(prog["Iterations"]) == len(FUN) and np.array_equal(prog["Function_Value"], np.asarray(FUN))
         assert np.array_equal(prog["X_opt"][0], X_opt[0])
+    back = so.load_progress()                           # the manual restart of the reference scripts: X_0 = DAL_file['X_opt']
+    assert np.array_equal(np.asarray(back["X_opt"])[0], X_opt[0]) and int(back["Iterations"]) == len(FUN)
 
     if DIM == 512:   # config 1 acceptance: CG converges to the top eigenpair
         lam, vec = np.linalg.eigh(M)
