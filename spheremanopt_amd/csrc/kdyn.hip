@@ -505,8 +505,8 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        if (!(N == 8 || N == 16 || N == 24 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128 || N == 256)) {
-            set_error("KDYN: npts must be one of 8,16,24,32,48,64,96,128,256 (got %d)", N);
+        if (!(N == 8 || N == 16 || N == 24 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128 || N == 192 || N == 256)) {
+            set_error("KDYN: npts must be one of 8,16,24,32,48,64,96,128,192,256 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
         if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
@@ -583,6 +583,7 @@ public:
             case 48: return f(std::integral_constant<int, 48>());
             case 96: return f(std::integral_constant<int, 96>());
             case 192: return f(std::integral_constant<int, 192>());
+            case 288: return f(std::integral_constant<int, 288>());
             case 384: return f(std::integral_constant<int, 384>());
         }
         set_error("KDYN: unsupported grid %d", g.G);

@@ -104,10 +104,12 @@ def test_size_independent_properties():
     dom.drop_contexts()
 
 
-def test_known_answer_single_mode_decay():
+@pytest.mark.parametrize("N", [32, 192])
+def test_known_answer_single_mode_decay(N):
     """U = 0, B = (0, cos 3x, 0): every CNAB1 step multiplies the mode by (1/dt - 9/2Rm)/(1/dt + 9/2Rm) — an answer that does not
-    come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost."""
-    N, n, dt, Rm = 32, 9, 1e-2, 1.3
+    come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost.  N = 192 (G = 288 = 4*4*2*3*3): a size whose
+    oracle run would take minutes is checked through this closed form."""
+    n, dt, Rm = 9, 1e-2, 1.3
     dom = kdyn.KDynDomain(N)
     G = dom.G
     x = 2. * np.pi * np.arange(G) / G
