@@ -48,7 +48,8 @@ def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
 
 @pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [(8, 2, "Final", "Discrete", True, 1), (16, 2, "Integrated", "Discrete", False, 3),
                                                           (16, 2, "Final", "Continuous", True, 2), (8, 4, "Final", "Discrete", False, 1),
-                                                          (8, 4, "Integrated", "Continuous", True, 1), (32, 2, "Final", "Discrete", True, 4)])
+                                                          (8, 4, "Integrated", "Continuous", True, 1), (32, 2, "Final", "Discrete", True, 4),
+                                                          (16, 8, "Final", "Discrete", True, 1)])
 def test_slab_driver_matches_oracle(tmp_path, N, world, cost, adj, keep, chunks):
     """keep = the forward solve keeps B_n on the grid side (the adjoint's inverse exchange then carries one field group);
     chunks = pipelining granularity of the local z slab (exchange buffers become [chunk][peer]...)."""

@@ -71,7 +71,8 @@ def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
 
 @pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [(16, 2, "Final", "Discrete", True, 1), (32, 4, "Integrated", "Discrete", False, 1),
                                                           (16, 2, "Final", "Continuous", True, 2), (48, 4, "Final", "Discrete", True, 3),
-                                                          (32, 2, "Final", "Discrete", False, 4), (64, 2, "Integrated", "Continuous", True, 2)])
+                                                          (32, 2, "Final", "Discrete", False, 4), (64, 2, "Integrated", "Continuous", True, 2),
+                                                          (32, 2, "Integrated", "Discrete", True, 1)])   # 24 local planes: the halved y-pass tile
 def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep, chunks):
     import torch.multiprocessing as mp
     from oracle.kdyn import KDynOracle
@@ -125,3 +126,49 @@ def test_rccl_call_path_on_one_rank(tmp_path, chunks):
     assert float(r["J1"]) == float(r["J0"])
     assert float(r["eB"]) == 0.0 and float(r["eU"]) == 0.0
     assert abs(float(r["ip"]) - float(r["ip0"])) < 1e-15
+
+
+def _big_worker(rank, world, port, N, n, chunks, out):
+    sys.path.insert(0, ROOT)
+    os.environ["SMO_SLAB_CHUNKS"] = str(chunks)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from spheremanopt_amd import kdyn
+        from spheremanopt_amd.kdyn_slab import SlabKDyn
+        G = 3 * N // 2
+        B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+        s = SlabKDyn(N, 1., 1e-3, n, "Final")
+        assert s.K == chunks
+        J = s.forward([s.local_slab(B), s.local_slab(U)])
+        g = s.adjoint("Discrete")
+        gB, gU = s.gather_full(g[0]), s.gather_full(g[1])
+        if rank == 0:
+            np.savez(out, J=J, gB=gB, gU=gU)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,world,chunks", [(128, 4, 1), (256, 4, 2)])
+def test_bench_size_slabs_agree_with_the_single_gpu_path(tmp_path, N, world, chunks):
+    """The slab geometries of the multi-GPU benchmark sizes (128^3: thin slabs; 256^3: the half-size tiles of the G = 384 kernels, two
+    pipelined chunks) against the monolithic single-GPU path on the same inputs: same kernels, another summation order only in J."""
+    import torch.multiprocessing as mp
+    from spheremanopt_amd import kdyn
+    n = 2
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    dom = kdyn.KDynDomain(N)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args = [dom, 1., 1e-3, n, n, buf, "Final", "Discrete"]
+    J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    dom.drop_contexts()
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_big_worker, args=(world, _free_port(), N, n, chunks, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert abs(float(r["J"]) - J0) <= 1e-12 * abs(J0)
+    assert rel(r["gB"], g0[0]) < 1e-12 and rel(r["gU"], g0[1]) < 1e-12
