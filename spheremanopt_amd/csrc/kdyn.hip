@@ -593,8 +593,8 @@ public:
     // (<= 37-49 KB => 3-4 workgroups per CU) and the butterflies per thread stay what they are at G = 192.
     template <int L> struct Shape {
         static constexpr int H = (L > 192) ? 2 : 1;
-        static constexpr int ZNBT = 4 / H, ZNT = 192;          // z passes: row triples per workgroup (12 / 6 FFTs)
-        static constexpr int ZA_NBT = 2 / H, ZA_NT = 192;      // adjoint update: row triples x 2 fields
+        static constexpr int ZNBT = 2 / H, ZNT = 256;          // z passes: row triples per workgroup (6 / 3 FFTs: 18 KB of LDS => 8 workgroups per CU)
+        static constexpr int ZA_NBT = 1, ZA_NT = 192;          // adjoint update: one row triple x 2 fields (6 FFTs)
         static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
         static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: (y,z) points per workgroup (12 / 6 FFTs); 128-B runs at G=192
         static constexpr int XTA = 4 / H, XANT = 192;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
