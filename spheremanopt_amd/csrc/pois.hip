@@ -30,70 +30,81 @@ using cd = std::complex<double>;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------
-// batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 64x64 tile per workgroup, 4 waves of 32x32,
-// 32-deep K slices staged through LDS with the next slice prefetched into registers
+// batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 32-deep K slices staged through LDS with the next slice
+// prefetched into registers
 // ---------------------------------------------------------------------------------------------------------
 struct GemmDesc { const double* A; const double* B; double* C; };
 
+// TM x TN tile per workgroup (4 waves as 2 x 2, each (TM/2) x (TN/2) = MI x NI MFMA tiles).  The products of this path are small
+// (M, N, K of a few hundred, 2-17 of them per launch): 32 x 32 tiles give 4x more workgroups than 64 x 64 and keep the 256 CUs busy.
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ descs, int M, int N, int K) {
     constexpr int KT = 32;                                   // K slice per LDS stage
+    constexpr int MI = TM / 32, NI = TN / 32, NA = TM * KT / 256, NBL = KT * TN / 256;
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "tile = multiples of 32");
     const GemmDesc d = descs[blockIdx.z];
-    __shared__ double As[64][KT + 1];
-    __shared__ double Bs[KT][65];
+    __shared__ double As[TM][KT + 1];
+    __shared__ double Bs[KT][TN + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
     const int lr = lane & 15, lk = lane >> 4;
-    double4_t acc[2][2];
+    double4_t acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NI; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
     // the next slice is fetched into registers while the current one is multiplied (the launches are small: latency, not bandwidth)
-    double ra[8], rb[8];
+    double ra[NA], rb[NBL];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
             const int ar = idx / KT, ac = idx % KT;
             ra[i] = (m0 + ar < M && k0 + ac < K) ? d.A[(size_t)(m0 + ar) * K + k0 + ac] : 0.0;
-            const int br = idx >> 6, bc = idx & 63;
+        }
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            const int idx = tid + i * 256;
+            const int br = idx / TN, bc = idx % TN;
             rb[i] = (k0 + br < K && n0 + bc < N) ? d.B[(size_t)(k0 + br) * N + n0 + bc] : 0.0;
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += KT) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + i * 256;
-            As[idx / KT][idx % KT] = ra[i];
-            Bs[idx >> 6][idx & 63] = rb[i];
-        }
+        for (int i = 0; i < NA; ++i) { const int idx = tid + i * 256; As[idx / KT][idx % KT] = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) { const int idx = tid + i * 256; Bs[idx / TN][idx % TN] = rb[i]; }
         __syncthreads();
         if (k0 + KT < K) fetch(k0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 4) {
-            double a[2], b[2];
+            double a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[wm + 16 * i + lr][kk + lk];       // A[row = lane&15][k = lane>>4]
+            for (int i = 0; i < MI; ++i) a[i] = As[wm + 16 * i + lr][kk + lk];       // A[row = lane&15][k = lane>>4]
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kk + lk][wn + 16 * j + lr];       // B[k = lane>>4][col = lane&15]
+            for (int j = 0; j < NI; ++j) b[j] = Bs[kk + lk][wn + 16 * j + lr];       // B[k = lane>>4][col = lane&15]
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                            // C: col = lane&15, row = (lane>>4) + 4*reg
                 const int row = m0 + wm + 16 * i + lk + 4 * r, col = n0 + wn + 16 * j + lr;
                 if (row < M && col < N) d.C[(size_t)row * N + col] = acc[i][j][r];
             }
+}
+constexpr int GEMM_T = 32;
+static inline void launch_gemm(hipStream_t stream, const GemmDesc* descs, int n, int M, int N, int K) {
+    hipLaunchKernelGGL((pois_gemm<GEMM_T, GEMM_T>), dim3((N + GEMM_T - 1) / GEMM_T, (M + GEMM_T - 1) / GEMM_T, n), dim3(256), 0, stream, descs, M, N, K);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -447,7 +458,7 @@ public:
     int run(const Phase& p, int count = -1) {
         const int n = count < 0 ? p.n : count;
         ScopedTimer t(timing, k_gemm, stream);
-        hipLaunchKernelGGL(pois_gemm, dim3((p.N + 63) / 64, (p.M + 63) / 64, n), dim3(256), 0, stream, p.d, p.M, p.N, p.K);
+        launch_gemm(stream, p.d, n, p.M, p.N, p.K);
         return SMO_OK;
     }
     // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
@@ -836,11 +847,11 @@ public:
         if (e == hipSuccess) {
             const int M2a = 2 * a;
             if (to_coeff) {
-                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d, M2a, Nz, Nx);
-                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d + 1, M2a, Nz, Nz);
+                launch_gemm(stream, d, 1, M2a, Nz, Nx);
+                launch_gemm(stream, d + 1, 1, M2a, Nz, Nz);
             } else {
-                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (M2a + 63) / 64, 1), dim3(256), 0, stream, d, M2a, Nz, Nz);
-                hipLaunchKernelGGL(pois_gemm, dim3((Nz + 63) / 64, (Nx + 63) / 64, 1), dim3(256), 0, stream, d + 1, Nx, Nz, M2a);
+                launch_gemm(stream, d, 1, M2a, Nz, Nz);
+                launch_gemm(stream, d + 1, 1, Nx, Nz, M2a);
             }
             e = hipStreamSynchronize(stream);
         }
@@ -901,7 +912,7 @@ public:
     }
     int run(const Phase& p) {
         ScopedTimer t(timing, k_gemm, stream);
-        hipLaunchKernelGGL(pois_gemm, dim3((p.N + 63) / 64, (p.M + 63) / 64, p.n), dim3(256), 0, stream, p.d, p.M, p.N, p.K);
+        launch_gemm(stream, p.d, p.n, p.M, p.N, p.K);
         return SMO_OK;
     }
     int apply(const double2* S, const double* in, double* out, double* xout, int nin, int nout, int xo) {
