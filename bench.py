@@ -369,6 +369,26 @@ def main():
             if not cfg["slab_J_matches_single_gpu"]:
                 raise RuntimeError("slab-decomposed J %r differs from the single-GPU J %r" % (cfg["J"], cfg["J_single_gpu"]))
             per_step_units = 1.0 / world          # ONE gradient is shared by all ranks (value = steps / time)
+            if not a.no_secondary:
+                # the other way to use N GPUs (line-search trial points, Taylor-test perturbations, ensembles): one independent gradient
+                # per rank, no exchange at all.  Reported next to the slab figure, never as `value`.  bench_kdyn runs with world=1 here (no
+                # barrier inside), so a rank that fails still reaches the all_reduce below.
+                el2, st2, info, fail = 0.0, 2, {}, 0.0
+                try:
+                    torch.cuda.empty_cache()
+                    b = argparse.Namespace(**{**vars(a), "steps": 2, "warmup": 1, "no_cpu_baseline": True})
+                    torch.distributed.barrier()
+                    st2, _, el2, _, _, info, _ = bench_kdyn(b, torch, rank, 1)
+                except Exception as e2:
+                    fail, info = 1.0, {"error": repr(e2)}
+                t2 = torch.tensor([el2, fail], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
+                torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+                if float(t2[1].item()) > 0:
+                    cfg["independent_gradients"] = {"error": info.get("error", "failed on another rank")}
+                else:
+                    cfg["independent_gradients"] = {"value": st2 * world / float(t2[0].item()), "unit": "gradient evals/s", "scaling": "weak",
+                                                    "ms_per_gradient_per_gpu": 1e3 * float(t2[0].item()) / st2, "steps": st2, "warmup": 1,
+                                                    "checkpoint_interval": info["checkpoint_interval"], "y_side_stack_GB": info["y_side_stack_GB"]}
         except Exception as e:                   # keep the contract (one JSON line) even if the slab path fails on this node
             sys.stderr.write("rank %d: slab path failed (%r); falling back to independent replicas\n" % (rank, e))
             steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)

@@ -44,3 +44,23 @@ def test_kdyn_line_contract():
 def test_other_workloads_emit_one_line(wl):
     d = _run(["--workload", wl, "--steps", "1", "--warmup", "1", "--iters", "40", "--no-cpu-baseline"])
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and wl[:2].lower() in d["config"]["workload"].lower().replace("swift-hohenberg", "sh").replace("plane-poiseuille", "po")
+
+
+def test_two_rank_line_reports_slab_and_independent_gradients():
+    """The N>1 launch of the contract (torch.distributed.run, one rank per process) on the one GPU of the test box: ranks share cuda:0
+    and exchange through gloo.  One JSON line from rank 0, strong scaling, slab J equal to the single-GPU J, plus the exchange-free figure."""
+    env = dict(os.environ, PYTHONPATH=ROOT, SMO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--npts", "32", "--iters", "20", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "slab" in d["config"]["parallelism"], d["config"]
+    assert d["config"]["slab_J_matches_single_gpu"] and "slab_path_error" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]              # ONE gradient shared by the ranks
+    ig = d["config"]["independent_gradients"]
+    assert "error" not in ig and ig["scaling"] == "weak" and ig["value"] > 0
