@@ -41,6 +41,8 @@ struct Geom {
     size_t blk;   // slab-exchange layout: elements of one (chunk, peer) block (= field groups * 3 * al * m * Gzl)
     size_t cblk;  // elements between consecutive chunks (= W * 2 field groups * 3 * al * m * Gzl, whatever the number of groups in use,
                   // so that a chunk's region with one group lies inside its region with two)
+    size_t typ;   // Ty: elements between consecutive (component, kx) planes (G * Gzl + padding; the padding keeps the x pass's 3a
+                  // runs per tile off a power-of-two stride)
     int utile;    // x pass spectrum -> grid: 1 = write the tile-major layout of the internal U field (u_off), 0 = the flat X layout
     double Rm, dt;
 };
@@ -75,7 +77,7 @@ __device__ __forceinline__ size_t ys_row0(int c, int kx, const Geom& g) {
 }
 // x pass: offset of mode kx (global) of component c, flat local (y,z) index i, in Ty[3][a][G*Gzl]
 __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
-    return ((size_t)c * g.a + kx) * ((size_t)g.G * g.Gzl) + i;
+    return ((size_t)c * g.a + kx) * g.typ + i;
 }
 
 // The velocity field U is only ever read by the fused x passes, one (y,z) tile per workgroup, all x.  It is therefore kept
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * a + kx
     const int c = o / g.a, kx = o - c * g.a;
     const size_t zrow = ys_row0(c, kx, g) + z0;                               // + idx * Gzl + b
-    const size_t trow = (size_t)o * g.G * g.Gzl + z0;                          // + y * Gzl + b
+    const size_t trow = (size_t)o * g.typ + z0;                                // + y * Gzl + b
     if (INV) {
         auto ld0 = [&](int b, int pos) -> cplx {
             const int idx = wrap_pos(pos, g);
@@ -466,7 +468,9 @@ public:
     // The rank's z slab can be cut into K equal chunks (SMO_KD_SET_CHUNKS): the grid-side phases then work chunk by chunk and every
     // chunk of an exchange buffer is contiguous, so the host layer can overlap the exchange of one chunk with the work on another.
     int K = 1;
-    size_t tzc = 0, fldc = 0, ngc = 0;       // per chunk: tzb / K, fld / K, n_grid / K
+    size_t tzc = 0, fldc = 0, ngc = 0;       // per chunk: tzb / K, 3*a*typ, n_grid / K
+    static constexpr int TY_KMAX = 8;
+    size_t ty_pad = 0;
     cplx *d_stack = nullptr, *d_ty = nullptr, *d_G = nullptr, *d_nu = nullptr, *d_tw = nullptr;
     cplx *zs = nullptr, *ys = nullptr;      // Tz exchange buffers: z-pass side / y-pass side (one and the same when world == 1)
     double *d_U = nullptr, *d_part = nullptr;
@@ -497,7 +501,8 @@ public:
             set_error("KDYN: %d chunks do not divide the %d local z planes into even parts with G*Gz %% 4 == 0", k, g.Gzr);
             return SMO_ERR_ARG;
         }
-        K = k; g.Gzl = Gzc; tzc = tzb / K; fldc = fld / K; ngc = n_grid / K;
+        K = k; g.Gzl = Gzc; tzc = tzb / K; ngc = n_grid / K;
+        g.typ = (size_t)g.G * Gzc + (K <= TY_KMAX ? ty_pad : 0); fldc = (size_t)3 * g.a * g.typ;
         have_forward = false;
         return SMO_OK;
     }
@@ -518,10 +523,16 @@ public:
         nmode = (size_t)g.al * g.m * g.m;
         tzb = (size_t)3 * g.al * g.m * g.Gzl;
         n_ex = 2 * tzb * W;                              // two field groups (adjoint) x peers
-        fld = (size_t)3 * g.a * g.G * g.Gzl;
+        // One 128-byte line of padding per (component, kx) plane of Ty.  The x pass gathers 3a runs per tile, one per plane; with the
+        // natural stride 16*G*Gzl (a multiple of 64 KB at every supported size) they all fall on the same HBM channel: measured
+        // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
+        { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
+        if (ty_pad % 8 != 0) { set_error("KDYN: SMO_KD_TYPAD must be a multiple of 8 elements (one 128-byte line)"); return SMO_ERR_ARG; }
+        g.typ = (size_t)g.G * g.Gzl + ty_pad;
+        fld = (size_t)3 * g.a * ((size_t)g.G * g.Gzl + TY_KMAX * ty_pad);
         n_grid = (size_t)3 * g.G * g.G * g.Gzl;          // local slab of a grid vector: [3][G][G][Gzl]
         g.blk = tzb;
-        tzc = tzb; fldc = fld; ngc = n_grid;
+        tzc = tzb; fldc = (size_t)3 * g.a * g.typ; ngc = n_grid;
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
