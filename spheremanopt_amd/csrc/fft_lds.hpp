@@ -175,28 +175,33 @@ __device__ __forceinline__ void inplace_stage(int tid, const cplx* __restrict__ 
     }
 }
 
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
 template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS> struct InplaceTail {
-    template <class StoreN>
-    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, const cplx* tw, StoreN stN) {
+    template <class StoreN, class PreLast>
+    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, const cplx* tw, StoreN stN, PreLast pre) {
         constexpr int R = radix_of(N);
         auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
         if constexpr (N / R == 1) {
+            pre();
             inplace_stage<L, N, S, INV, NB, NT, BFAST, LAST_LDS>(tid, tw, ldL, stN);
         } else {
             inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
             __syncthreads();
-            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN);
+            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN, pre);
         }
     }
 };
 
-template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class Load0, class StoreN>
-__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, const cplx* tw, int tid, Load0 ld0, StoreN stN) {
+// `pre` runs right before the last stage: the place to issue global loads whose results are needed after the transform (they are
+// then in flight during the last stage instead of being waited for after it, and live in registers for one stage only).
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class Load0, class StoreN, class PreLast = NoPrefetch>
+__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, const cplx* tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
     constexpr int R0 = radix_of(L);
     static_assert(L / R0 > 1, "transform needs at least two stages");
     inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
     __syncthreads();
-    InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN);
+    InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN, pre);
 }
 
 }  // namespace smo

@@ -329,17 +329,37 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     if (MODE == X_FROM_GRID) {
         fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
     } else {
-        fft_inplace<L, true, NB, NT, true, false, true>(buf, LD, tw, tid, ld_spec, st_buf);
+        // pointwise products on the grid; item = (x, p), p fastest.  The velocity at a thread's items is requested before the last
+        // stage of the inverse transform and arrives while that stage runs.
+        // (Forward pass up to G = 288 only: measured 112 -> 103 us at G = 192; at G = 384 the extra registers cost a wave per SIMD
+        // (1059 -> 1148 us), and the adjoint pass, which also waits for B_f from the LDS, does not change.)
+        constexpr bool PREF = (MODE == X_FUSED_FWD && L <= 288);
+        constexpr int UCNT = (HP * L + NT - 1) / NT;
+        cplx Ug[PREF ? UCNT : 1][3];
+        auto load_U = [&](int i) {
+            const int t = tid + i * NT, x = t / HP, p = t - x * HP;
+            if (t < HP * L && line_ok(p))
+                for (int c = 0; c < 3; ++c) {
+                    const double* q = gridU + u_off(c, x, i0 + 2 * p, g);
+                    Ug[PREF ? i : 0][c] = mk(q[0], q[1]);
+                }
+        };
+        fft_inplace<L, true, NB, NT, true, false, true>(buf, LD, tw, tid, ld_spec, st_buf, [&]() {
+            if (PREF) {
+#pragma unroll
+                for (int i = 0; i < UCNT; ++i) load_U(i);
+            }
+        });
         __syncthreads();
-        // pointwise products on the grid; item = (x, p), p fastest
-        for (int t = tid; t < HP * L; t += NT) {
-            const int x = t / HP, p = t - x * HP;
-            if (!line_ok(p)) continue;
+#pragma unroll
+        for (int i = 0; i < UCNT; ++i) {
+            const int t = tid + i * NT, x = t / HP, p = t - x * HP;
+            if (t >= HP * L || !line_ok(p)) continue;
             cplx A[3], U[3];                        // .re / .im = the two real lines of the pair
+            if (!PREF) load_U(i);
             for (int c = 0; c < 3; ++c) {
                 A[c] = buf[(c * HP + p) * LD + x];
-                const double* q = gridU + u_off(c, x, i0 + 2 * p, g);
-                U[c] = mk(q[0], q[1]);
+                U[c] = Ug[PREF ? i : 0][c];
             }
             if (MODE == X_FUSED_FWD) {              // EMF = U x B
                 for (int c = 0; c < 3; ++c) {
