@@ -149,13 +149,17 @@ enum {
     SMO_KD_ADJ_INIT = 10,     /* i0 = adjoint_type: terminal condition from snapshot N                                               */
     SMO_KD_ADJ_A = 11,        /* i0 = snapshot index: z inverse pass of curl(G^) [and of B^_i0]       [exchange z->y, 1 or 2 groups:
                                  1 when smo_get(ctx, 1) > 0 (grid-side states kept by the forward solve) and i0 < n_iters, else 2]   */
-    SMO_KD_ADJ_B = 12,        /* i0 = snapshot index: y passes, fused x pass (two cross products), y passes [exchange y->z, 2 groups] */
-    SMO_KD_ADJ_C = 13,        /* i0 = snapshot index: z forward passes + G^, nu^ updates                                             */
+    SMO_KD_ADJ_B = 12,        /* i0 = snapshot index: y pass(es), fused x pass (two cross products; the second one, (curl G) x B_i0, is
+                                 added to a running sum that stays on the grid side), y pass of the first [exchange y->z, 1 group]    */
+    SMO_KD_ADJ_C = 13,        /* i0 = snapshot index: z forward pass + G^ update                                                     */
     SMO_KD_SYNC = 14,         /* wait for the context's stream                                                                     */
-    SMO_KD_SET_CHUNKS = 15    /* i0 = K: cut the local z slab into K equal chunks.  The grid-side phases (G2C_A, C2G_B, FWD_B, ADJ_B) then
+    SMO_KD_SET_CHUNKS = 15,   /* i0 = K: cut the local z slab into K equal chunks.  The grid-side phases (G2C_A, C2G_B, FWD_B, ADJ_B, NU_B) then
                                  take the chunk index in i1 and the exchange buffers become [chunk][peer][field group][3][a/W][m][G/W/K]:
                                  every chunk is one contiguous all-to-all, so the host layer can overlap the exchange of one chunk with
                                  the grid work on another.  K = 1 (default) is the layout described above.                            */
+    SMO_KD_NU_B = 16,         /* after the last adjoint step; i1 = chunk: y pass of the running sum                 [exchange y->z, 1 group] */
+    SMO_KD_NU_C = 17          /* z forward pass of it, projection, factor -dt  ->  nu^ (= the reference's nu recursion: it acts as the
+                                 identity on the solenoidal sums it carries, so the transforms are applied once instead of per step)   */
 };
 int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double* out);
 

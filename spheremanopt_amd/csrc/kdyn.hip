@@ -148,15 +148,14 @@ __device__ __forceinline__ void cnab_mode(const double k[3], double k2, double a
         V1[c] = mk((r[c].re - k[c] * kr.re) / alpha - k[c] * kv.re, (r[c].im - k[c] * kr.im) / alpha - k[c] * kv.im);
 }
 
-enum { ZF_PLAIN = 0, ZF_FWD_UPDATE = 1, ZF_ADJ_UPDATE = 2 };
+enum { ZF_PLAIN = 0, ZF_FWD_UPDATE = 1, ZF_ADJ_UPDATE = 2, ZF_NU = 3 };
 
-// NF = number of transformed fields (1: plain / forward update, 2: adjoint update: F1 spectra, then F2' spectra)
+// ZF_PLAIN: truncated spectrum;  ZF_FWD_UPDATE: B^_{n+1};  ZF_ADJ_UPDATE: G^ update with forcing F1 = F[(curl G) x U] (minus 2 B_f if
+// integrated);  ZF_NU: nu^ = -dt P(F[sum_n (curl G_n) x B_n]) from the accumulated product (see the fused adjoint x pass)
 template <int L, int MODE, int NBT, int NT>
-__global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA, const cplx* __restrict__ inB, cplx* out0, cplx* out1,
-                                                   const cplx* state0 /* may alias out0 */, const cplx* snap,
-                                                   const cplx* __restrict__ tw_g, Geom g, double scale, int integrated) {
-    constexpr int NF = (MODE == ZF_ADJ_UPDATE) ? 2 : 1;
-    constexpr int NB = 3 * NBT * NF;
+__global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA, cplx* out0, const cplx* state0 /* may alias out0 */,
+                                                   const cplx* snap, const cplx* __restrict__ tw_g, Geom g, double scale, int integrated) {
+    constexpr int NB = 3 * NBT;
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -165,12 +164,11 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
     const int nrt = g.al * g.m;
     const int rt0 = blockIdx.x * NBT;
     const size_t cs = (size_t)nrt * g.m;
-    // b = (f * NBT + tt) * 3 + c
+    // b = tt * 3 + c
     auto ld0 = [&](int b, int pos) -> cplx {
-        const int c = b % 3, ft = b / 3, f = ft / NBT, tt = ft - f * NBT, rt = rt0 + tt;
+        const int c = b % 3, tt = b / 3, rt = rt0 + tt;
         if (rt >= nrt) return mk(0, 0);
-        const cplx* src = (f == 0) ? inA : inB;
-        return src[zs_off(c, rt, pos, g)];
+        return inA[zs_off(c, rt, pos, g)];
     };
     if (MODE == ZF_PLAIN) {
         auto stN = [&](int b, int pos, cplx v) {
@@ -194,7 +192,19 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
         const double D = k2 / g.Rm, alpha = 1.0 / g.dt + 0.5 * D, beta = 1.0 / g.dt - 0.5 * D;
         const size_t e = (size_t)rt * g.m + iz;
         cplx E[3], V0[3], V1[3];
-        for (int c = 0; c < 3; ++c) { E[c] = scale * buf[(tt * 3 + c) * L + pos]; V0[c] = state0[c * cs + e]; }
+        for (int c = 0; c < 3; ++c) E[c] = scale * buf[(tt * 3 + c) * L + pos];
+        if (MODE == ZF_NU) {
+            if (k2 == 0.0) {
+                for (int c = 0; c < 3; ++c) V1[c] = mk(0, 0);
+            } else {
+                const double ik2 = 1.0 / k2;
+                const cplx kf = mk((k[0] * E[0].re + k[1] * E[1].re + k[2] * E[2].re) * ik2, (k[0] * E[0].im + k[1] * E[1].im + k[2] * E[2].im) * ik2);
+                for (int c = 0; c < 3; ++c) V1[c] = mk(-g.dt * (E[c].re - k[c] * kf.re), -g.dt * (E[c].im - k[c] * kf.im));
+            }
+            for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
+            continue;
+        }
+        for (int c = 0; c < 3; ++c) V0[c] = state0[c * cs + e];
         if (MODE == ZF_FWD_UPDATE) {
             cplx F[3];                                  // N^ = i k x E^
             for (int c = 0; c < 3; ++c) {
@@ -202,30 +212,12 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
                 F[c] = mul_i(mk(k[c1] * E[c2].re - k[c2] * E[c1].re, k[c1] * E[c2].im - k[c2] * E[c1].im));
             }
             cnab_mode(k, k2, alpha, beta, V0, F, V1);
-            for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
         } else {
-            // adjoint: G update (forcing F1 = F[(curl G) x U], minus 2 B_f if integrated), nu update (forcing -F[(curl G) x B_f])
-            cplx F2[3], nu0[3], nu1[3];
-            for (int c = 0; c < 3; ++c) {
-                F2[c] = scale * buf[((NBT + tt) * 3 + c) * L + pos];
-                nu0[c] = out1[c * cs + e];
-                if (integrated) { cplx bf = snap[c * cs + e]; E[c] = mk(E[c].re - 2.0 * bf.re, E[c].im - 2.0 * bf.im); }
-            }
+            if (integrated)
+                for (int c = 0; c < 3; ++c) { cplx bf = snap[c * cs + e]; E[c] = mk(E[c].re - 2.0 * bf.re, E[c].im - 2.0 * bf.im); }
             cnab_mode(k, k2, alpha, beta, V0, E, V1);
-            if (k2 == 0.0) {
-                for (int c = 0; c < 3; ++c) nu1[c] = mk(-nu0[c].re, -nu0[c].im);
-            } else {
-                const double ik2 = 1.0 / k2;
-                const cplx kn = mk((k[0] * nu0[0].re + k[1] * nu0[1].re + k[2] * nu0[2].re) * ik2,
-                                   (k[0] * nu0[0].im + k[1] * nu0[1].im + k[2] * nu0[2].im) * ik2);
-                const cplx kf = mk((k[0] * F2[0].re + k[1] * F2[1].re + k[2] * F2[2].re) * ik2,
-                                   (k[0] * F2[0].im + k[1] * F2[1].im + k[2] * F2[2].im) * ik2);
-                for (int c = 0; c < 3; ++c)       // nu - 2 k (k.nu)/k2 + dt P(-F2')
-                    nu1[c] = mk(nu0[c].re - 2.0 * k[c] * kn.re - g.dt * (F2[c].re - k[c] * kf.re),
-                                nu0[c].im - 2.0 * k[c] * kn.im - g.dt * (F2[c].im - k[c] * kf.im));
-            }
-            for (int c = 0; c < 3; ++c) { out0[c * cs + e] = V1[c]; out1[c * cs + e] = nu1[c]; }
         }
+        for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
     }
 }
 
@@ -326,6 +318,9 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         });
         return;
     }
+    constexpr bool ACC = (MODE == X_FUSED_ADJ);
+    constexpr int SCNT = ((L / 3) * NF * 3 * HP + NT - 1) / NT;        // items per thread of the final split / store loop
+    cplx old_sum[ACC ? SCNT : 1][2];
     if (MODE == X_FROM_GRID) {
         fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
     } else {
@@ -378,19 +373,36 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
             }
         }
         __syncthreads();
-        fft_inplace<L, false, NB, NT, true, true, true>(buf, LD, tw, tid, [&](int b, int pos) { return buf[b * LD + pos]; }, st_buf);
+        // group B of the adjoint pass is a running sum: its old values are requested before the last stage of the transform
+        fft_inplace<L, false, NB, NT, true, true, true>(buf, LD, tw, tid, [&](int b, int pos) { return buf[b * LD + pos]; }, st_buf, [&]() {
+            if (ACC) {
+#pragma unroll
+                for (int i = 0; i < SCNT; ++i) {
+                    const int t = tid + i * NT, p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3);
+                    if (t < (L / 3) * NF * 3 * HP && fc >= 3 && line_ok(p)) {
+                        const cplx* q = sp.outB + tx_off(fc - 3, kx, i0 + 2 * p, g);
+                        old_sum[i][0] = q[0]; old_sum[i][1] = q[1];
+                    }
+                }
+            }
+        });
     }
     __syncthreads();
-    // split the two real lines' spectra and store kx = 0..a-1; item = ((kx*NF*3 + fc)*HP + p), p fastest
-    for (int t = tid; t < g.a * NF * 3 * HP; t += NT) {
+    // split the two real lines' spectra and store kx = 0..a-1 (a = L/3); item = ((kx*NF*3 + fc)*HP + p), p fastest
+#pragma unroll
+    for (int i = 0; i < SCNT; ++i) {
+        const int t = tid + i * NT;
+        if (t >= (L / 3) * NF * 3 * HP) break;
         const int p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3);
         if (!line_ok(p)) continue;
         const int c = fc % 3, f = fc / 3;
         const cplx Zk = buf[(fc * HP + p) * LD + kx];
         const cplx Zm = conj(buf[(fc * HP + p) * LD + ((kx == 0) ? 0 : L - kx)]);
         cplx* dst = ((f == 0) ? sp.outA : sp.outB) + tx_off(c, kx, i0 + 2 * p, g);
-        dst[0] = 0.5 * (Zk + Zm);
-        dst[1] = mul_mi(0.5 * (Zk - Zm));
+        cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
+        if (ACC && f == 1) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
+        dst[0] = v0;
+        dst[1] = v1;
     }
 }
 
@@ -562,7 +574,7 @@ public:
         if (ck == 0) {                                       // smallest interval that fits the free HBM (keep 8 GB + work buffers spare)
             size_t free_b = 0, total_b = 0;
             SMO_HIP(hipMemGetInfo(&free_b, &total_b));
-            const size_t work = (2 * n_ex + 2 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)8 << 30);
+            const size_t work = (2 * n_ex + 3 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)8 << 30);
             for (ck = 1; ck < cfg.n_iters && stack_elems(ck) * sizeof(cplx) + work > free_b; ++ck) {}
         }
         if (ck > cfg.n_iters) ck = cfg.n_iters;
@@ -575,13 +587,14 @@ public:
             size_t free_b = 0, total_b = 0;
             SMO_HIP(hipMemGetInfo(&free_b, &total_b));
             const size_t need = (size_t)cfg.n_iters * fld * sizeof(cplx);
-            const size_t rest = (2 * n_ex + 2 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)16 << 30);
+            const size_t rest = (2 * n_ex + 3 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)16 << 30);
             if (ck == 1 && !(env && atoi(env) == 0) && need + rest < free_b) {
                 SMO_TRY(pool.alloc(&d_tystack, (size_t)cfg.n_iters * fld));
                 stack_bytes += need;
             }
         }
         SMO_TRY(pool.alloc(&d_ty, 2 * fld));
+        SMO_TRY(pool.alloc(&d_acc, fld));
         if (W == 1) { SMO_TRY(pool.alloc(&zs, n_ex)); ys = zs; }      // slabs: the host layer supplies zs / ys (SMO_KD_SET_BUFFERS)
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
@@ -596,9 +609,9 @@ public:
         k_yi = timing.add_class("kd_y_pass<inv>", 3 * (S1 + S2));
         k_yf = timing.add_class("kd_y_pass<fwd>", 3 * (S1 + S2));
         k_xf = timing.add_class("kd_x_pass<fused_fwd>", 3 * (2 * (S2 + S3) + 3 * S3));           // 3 c2r + 3 r2c passes + pointwise (read B,U write EMF)
-        k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3));           // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2)
+        k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3));           // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2; the running sum's read is not counted)
         k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0);         // 3 z passes + step (read B,N; write B, snapshot)
-        k_zfa = timing.add_class("kd_z_forward<adj_update>", 6 * (S1 + S0) + 24 * S0);
+        k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0);         // F1 only: F2 is summed on the grid side (nu_B / nu_C)
         k_misc = timing.add_class("kd_misc(setup/terminal/energy/grid io)", 0);
         return SMO_OK;
     }
@@ -625,7 +638,6 @@ public:
     template <int L> struct Shape {
         static constexpr int H = (L > 192) ? 2 : 1;
         static constexpr int ZNBT = 2 / H, ZNT = 256;          // z passes: row triples per workgroup (6 / 3 FFTs: 18 KB of LDS => 8 workgroups per CU)
-        static constexpr int ZA_NBT = 1, ZA_NT = 192;          // adjoint update: one row triple x 2 fields (6 FFTs)
         static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
         static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: (y,z) points per workgroup (12 / 6 FFTs); 128-B runs at G=192
         static constexpr int XTA = 4 / H, XANT = 192;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
@@ -682,7 +694,7 @@ public:
         const double* grid_in = (mode == X_FROM_GRID) ? vec_in : Uk;
         double* grid_out = to_U ? Uk : vec_out;
         cplx *tA = d_ty + (size_t)k * fldc, *tB = d_ty + fld + (size_t)k * fldc;
-        const XSpec sp{inA ? inA : tA, inB ? inB : tB, tA, tB};
+        const XSpec sp{inA ? inA : tA, inB ? inB : tB, tA, mode == X_FUSED_ADJ ? d_acc + (size_t)k * fldc : tB};
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
@@ -698,10 +710,9 @@ public:
             return SMO_OK;
         });
     }
-    // z-side exchange buffer (field groups 0 [and 1]) -> coefficients / time-step update
-    int z_forward(int mode, cplx* out0, cplx* out1, const cplx* state0, const cplx* snp) {
-        const Geom g = geom(mode == ZF_ADJ_UPDATE ? 2 : 1);
-        const cplx *inA = zs, *inB = zs + tzc;
+    // z-side exchange buffer (one field group) -> coefficients / time-step update
+    int z_forward(int mode, cplx* out0, const cplx* state0, const cplx* snp) {
+        const Geom g = geom(1);
         const double scale = 1.0 / ((double)g.G * g.G * g.G);
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
         return with_L([&](auto l) {
@@ -709,13 +720,13 @@ public:
             using S = Shape<L>;
             const int k = mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc);
             ScopedTimer t(timing, k, stream);
-            if (mode == ZF_ADJ_UPDATE) {
-                const int nwg = (g.al * g.m + S::ZA_NBT - 1) / S::ZA_NBT;
-                hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, S::ZA_NBT, S::ZA_NT>), dim3(nwg), dim3(S::ZA_NT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
-            } else {
-                const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
-                if (mode == ZF_PLAIN) hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
-                else hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, inA, inB, out0, out1, state0, snp, d_tw, g, scale, integ);
+            const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
+            const dim3 grid(nwg), block(S::ZNT);
+            switch (mode) {
+                case ZF_PLAIN: hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
+                case ZF_FWD_UPDATE: hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
+                case ZF_ADJ_UPDATE: hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
+                default: hipLaunchKernelGGL((kd_z_forward<L, ZF_NU, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
             }
             return SMO_OK;
         });
@@ -736,11 +747,12 @@ public:
         SMO_TRY(x_pass(X_FUSED_FWD, k, nullptr, nullptr, ty));
         return y_pass(false, 0, 1, tyw(0, k), k);
     }
-    int fwd_C(int n) { return z_forward(ZF_FWD_UPDATE, snap(n + 1), nullptr, snap(n), nullptr); }
+    int fwd_C(int n) { return z_forward(ZF_FWD_UPDATE, snap(n + 1), snap(n), nullptr); }
     int adj_init(int adjoint_type) {
         ScopedTimer t(timing, k_misc, stream);
         hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(cfg.n_iters), d_G, d_nu, g, cfg.cost == SMO_COST_INTEGRATED ? 1 : 0,
                            adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
+        SMO_HIP(hipMemsetAsync(d_acc, 0, fld * sizeof(cplx), stream));
         return SMO_OK;
     }
     // inverse side of an adjoint step carries omega only (1 field group) when B_f was kept by the forward solve, else omega and B^_idx
@@ -755,13 +767,20 @@ public:
         SMO_TRY(y_pass(true, 0, nf, tyw(0, k), k));
         if (nf == 2) SMO_TRY(y_pass(true, 1, 2, tyw(1, k), k));
         SMO_TRY(x_pass(X_FUSED_ADJ, k, nullptr, nullptr, nullptr, nf == 1 ? tyslot(idx, k) : nullptr));
-        SMO_TRY(y_pass(false, 0, 2, tyw(0, k), k));
-        return y_pass(false, 1, 2, tyw(1, k), k);
+        return y_pass(false, 0, 1, tyw(0, k), k);
     }
-    int adj_C(int idx) { return z_forward(ZF_ADJ_UPDATE, d_G, d_nu, d_G, snap(idx)); }
+    int adj_C(int idx) { return z_forward(ZF_ADJ_UPDATE, d_G, d_G, snap(idx)); }
+    // The nu^ recursion of the reference, nu <- R nu - dt P F2_n (R = I - 2 k k^T/k^2, nu_N = 0), never leaves the solenoidal subspace,
+    // where R is the identity: nu_0 = -dt P sum_n F2_n exactly.  The fused adjoint x pass therefore adds its second product
+    // (curl G_n) x B_n, already transformed along x, to a running sum on the grid side (d_acc, the layout of Ty); the y and z passes,
+    // the projection and the factor -dt are applied ONCE after the last step (nu_B / nu_C) instead of once per step: one y pass and
+    // half a z pass less per adjoint step and, with slabs, one field group less to send back.
+    cplx* d_acc = nullptr;
+    int nu_B(int k) { return y_pass(false, 0, 1, d_acc + (size_t)k * fldc, k); }
+    int nu_C() { return z_forward(ZF_NU, d_nu, nullptr, nullptr); }
     // grid vector (local slab of the flat X layout) -> truncated coefficients, in two phases around the exchange
     int g2c_A(const double* X, int k) { SMO_TRY(x_pass(X_FROM_GRID, k, X, nullptr)); return y_pass(false, 0, 1, tyw(0, k), k); }
-    int g2c_C(cplx* out) { return z_forward(ZF_PLAIN, out, nullptr, nullptr, nullptr); }
+    int g2c_C(cplx* out) { return z_forward(ZF_PLAIN, out, nullptr, nullptr); }
     // coefficients -> grid; scaled = multiply by dt*alpha(k) first ("undo LHS", FWD_Solve_KDyn.py:985-989)
     int c2g_A(const cplx* C, bool scaled) { return z_inverse(scaled ? ZI_SCALE : ZI_PLAIN, C, 0, 1); }
     int c2g_B(double* X, int k) { SMO_TRY(y_pass(true, 0, 1, tyw(0, k), k)); return x_pass(X_TO_GRID, k, nullptr, X); }   // X == nullptr: the U field
@@ -838,6 +857,7 @@ public:
         int idx = cont ? N : N - 1;
         for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B(idx, 0)); SMO_TRY(adj_C(idx)); }
         SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0], 0));
+        SMO_TRY(nu_B(0)); SMO_TRY(nu_C());
         SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1], 0));
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
@@ -894,6 +914,8 @@ public:
             case SMO_KD_ADJ_A: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_A(i0); break;
             case SMO_KD_ADJ_B: if (!step_ok(i0, N) || !chunk_ok(i1)) return SMO_ERR_ARG; rc = adj_B(i0, i1); break;
             case SMO_KD_ADJ_C: if (!step_ok(i0, N)) return SMO_ERR_ARG; rc = adj_C(i0); break;
+            case SMO_KD_NU_B: if (!chunk_ok(i1)) return SMO_ERR_ARG; rc = nu_B(i1); break;
+            case SMO_KD_NU_C: rc = nu_C(); break;
             case SMO_KD_SYNC: SMO_HIP(hipStreamSynchronize(stream)); break;
             default: set_error("smo_kdyn_op: unknown op %d", op); return SMO_ERR_ARG;
         }

@@ -7,7 +7,8 @@ Parallel layout (the reference gets the same decomposition
     where the data is smallest (16*a*m*G bytes per component; after the y pass it would be 16*a*G*G, 1.5x more); the device
     kernels write/read the exchange buffers as [peer][field group][3][a/W][m][G/W], i.e. contiguous per peer.
   * when the HBM allows it the forward solve keeps B_n on the y side (after exchange and y pass) for every step, so an adjoint step
-    exchanges omega only on its inverse side: 5 field-group exchanges per forward+adjoint step pair instead of 6.
+    exchanges omega only on its inverse side; the adjoint's second product (the dJ/dU forcing) is summed over the steps on the grid
+    side and transformed once at the end: 4 field-group exchanges per forward+adjoint step pair (fwd 1+1, adj 1+1) instead of 6.
   * scalars (J, <x,y>) are all-reduced; the snapshot stack (1/W of it per GPU), the per-mode solves and the
     products need no communication.
 
@@ -26,7 +27,7 @@ from . import _capi
 
 # op codes of include/smo.h
 (SET_BUFFERS, EXCHANGE_ELEMS, G2C_A, G2C_C, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, ENERGY, ADJ_INIT, ADJ_A, ADJ_B, ADJ_C,
- SYNC, SET_CHUNKS) = range(16)
+ SYNC, SET_CHUNKS, NU_B, NU_C) = range(18)
 
 
 def _dist():
@@ -264,9 +265,14 @@ class SlabKDyn:
         for _ in range(self.n_iters):
             self.ops.phase(ADJ_A, idx)
             self._grid_stage(ADJ_B, idx, (self.buf_z, self.buf_y), (self.buf_y, self.buf_z),
-                             self.adj_groups if idx < self.n_iters else 2, 2)
+                             self.adj_groups if idx < self.n_iters else 2, 1)
             self.ops.phase(ADJ_C, idx)
             idx -= 1
+        # nu^: the second cross product was summed over the steps on the grid side; transform the sum once
+        for k in range(self.K):
+            self.ops.phase(NU_B, k=k)
+            self._exchange(self.buf_y, self.buf_z, 1, k)
+        self.ops.phase(NU_C)
         if out is None:
             out = [self.torch.empty(self.ops.vec_len, dtype=self.torch.float64, device=self.dev) for _ in range(2)]
         self._coeff_to_grid(1 if cont else 0, out[0])

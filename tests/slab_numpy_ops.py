@@ -6,7 +6,7 @@ import numpy as np
 from scipy import fft as sfft
 
 from oracle.kdyn import KDynOracle
-from spheremanopt_amd.kdyn_slab import (ADJ_A, ADJ_B, ADJ_C, ADJ_INIT, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, G2C_A, G2C_C)
+from spheremanopt_amd.kdyn_slab import (ADJ_A, ADJ_B, ADJ_C, ADJ_INIT, C2G_A, C2G_B, FWD_A, FWD_B, FWD_C, G2C_A, G2C_C, NU_B, NU_C)
 
 
 class NumpyOps:
@@ -130,6 +130,7 @@ class NumpyOps:
                 self.Gh = o.project(-2. * BN) / scale
                 self.Gh[:, o.zero] = 0.
             self.nu = np.zeros_like(self.Gh)
+            self.acc = {}                            # running sum of the second product, per chunk, on the grid side
         elif code in (ADJ_A, ADJ_B):
             kept = self.keeps_grid_states and i0 < self.n_iters      # B_f is on the grid side already: omega travels alone
             nf = 1 if kept else 2
@@ -141,17 +142,19 @@ class NumpyOps:
                 om = self._yx_to_grid(self._get_y(0, nf, k))
                 Bf = self.Bgrid[(i0, k)] if kept else self._yx_to_grid(self._get_y(1, 2, k))
                 F1, F2 = self._xy_from_grid(o.cross(om, self.U[..., zs])), self._xy_from_grid(o.cross(om, Bf))
-                self._put_y(F1, 0, 2, k)
-                self._put_y(F2, 1, 2, k)
+                self._put_y(F1, 0, 1, k)
+                self.acc[k] = self.acc[k] + F2 if k in self.acc else F2
         elif code == ADJ_C:
-            F1 = self._z_forward(self._get_z(0, 2)); F2 = -self._z_forward(self._get_z(1, 2))
+            F1 = self._z_forward(self._get_z(0, 1))
             if self.cost == "Integrated":
                 F1 = F1 - 2. * self.stack[i0]
-            nu, K = self.nu, o.K
-            nu_new = nu - 2. * K * (o.kdot(nu) / o.k2s) + self.dt * o.project(F2)
-            nu_new[:, o.zero] = -nu[:, o.zero]
             self.Gh = o.cnab_update(self.Gh, F1)
-            self.nu = nu_new
+        elif code == NU_B:
+            self._put_y(self.acc[k], 0, 1, k)
+        elif code == NU_C:
+            # nu <- R nu - dt P F2_n with nu_N = 0 (the reference's recursion) == -dt P sum_n F2_n: R is the identity on solenoidal fields
+            self.nu = -self.dt * o.project(self._z_forward(self._get_z(0, 1)))
+            self.nu[:, o.zero] = 0.
         else:
             raise ValueError(code)
 

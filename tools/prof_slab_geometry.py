@@ -42,7 +42,7 @@ def run(N, W, n_iters, keep):
     t_a = time.perf_counter() - t0
     tim = ops.ctx.timing()
     ker = {t["kernel"]: round(1e3 * t["total_ms"] / max(t["launches"], 1), 2) for t in tim if t["launches"]}
-    groups = 4 + (1 if ops.keeps_grid_states else 2)
+    groups = 3 + (1 if ops.keeps_grid_states else 2)     # fwd 1+1, adj (1 or 2)+1
     return {"N": N, "W": W, "kept_grid_states": bool(ops.keeps_grid_states), "fwd_us_per_step": 1e6 * t_f / n_iters,
             "adj_us_per_step": 1e6 * t_a / n_iters, "pair_us": 1e6 * (t_f + t_a) / n_iters, "kernel_avg_us": ker,
             "exchange_MB_sent_per_rank_per_pair": groups * ops.elems * 16 / 1e6 * (W - 1) / W}
