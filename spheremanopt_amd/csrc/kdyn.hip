@@ -266,6 +266,11 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
 // ---------------------------------------------------------------------------------------------------------
 enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
 
+// Row padding of the x pass's LDS tile (complex elements).  Lanes run over the NB transforms first, then over consecutive positions:
+// element (b, pos) starts at bank group (pad * b + pos) mod 16, and a 64-lane 16-byte access is conflict-free when each of the 16
+// groups gets 4 lanes, i.e. when the NB ranges [pad * b, pad * b + 64/NB) tile the line: pad ~ 64 / NB.
+constexpr int x_ld_pad(int NB) { return NB == 12 ? 5 : (NB == 6 ? 11 : 1); }
+
 // spectra of the x pass: field groups A / B are read from in* and written to out* (same layout; in == out means in place)
 struct XSpec {
     const cplx* inA;
@@ -280,7 +285,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
-    constexpr int LD = L + 1;
+    constexpr int LD = L + x_ld_pad(NB);
     const size_t plane = (size_t)g.G * g.Gzl;       // local (y,z) points
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
@@ -413,7 +418,7 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 __global__ __launch_bounds__(NT) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
-    __shared__ cplx buf[NB * (L + 1)];
+    __shared__ cplx buf[NB * (L + x_ld_pad(NB))];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
