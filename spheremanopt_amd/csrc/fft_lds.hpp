@@ -136,8 +136,18 @@ template <int NB, int PER, bool BFAST> __device__ __forceinline__ void split_ind
     else       { b = t / PER; j = t - b * PER; }
 }
 
-template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class Load, class Store>
-__device__ __forceinline__ void inplace_stage(int tid, const cplx* __restrict__ tw, Load ld, Store st) {
+// Twiddle table holding only exp(-2 pi i k / L) for k < L/2 (the other half is its negative): halves the table's LDS footprint.
+struct HalfTwiddles {
+    const cplx* t;
+    int half;
+    __device__ __forceinline__ cplx operator[](int i) const {
+        const cplx w = t[i < half ? i : i - half];
+        return i < half ? w : mk(-w.re, -w.im);
+    }
+};
+
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class TW, class Load, class Store>
+__device__ __forceinline__ void inplace_stage(int tid, TW tw, Load ld, Store st) {
     constexpr int R = radix_of(N);
     constexpr int M = N / R;
     constexpr int PER = L / R;
@@ -178,8 +188,8 @@ __device__ __forceinline__ void inplace_stage(int tid, const cplx* __restrict__ 
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS> struct InplaceTail {
-    template <class StoreN, class PreLast>
-    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, const cplx* tw, StoreN stN, PreLast pre) {
+    template <class TW, class StoreN, class PreLast>
+    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, TW tw, StoreN stN, PreLast pre) {
         constexpr int R = radix_of(N);
         auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
         if constexpr (N / R == 1) {
@@ -195,8 +205,8 @@ template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_L
 
 // `pre` runs right before the last stage: the place to issue global loads whose results are needed after the transform (they are
 // then in flight during the last stage instead of being waited for after it, and live in registers for one stage only).
-template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class Load0, class StoreN, class PreLast = NoPrefetch>
-__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, const cplx* tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class TW, class Load0, class StoreN, class PreLast = NoPrefetch>
+__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, TW tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
     constexpr int R0 = radix_of(L);
     static_assert(L / R0 > 1, "transform needs at least two stages");
     inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });

@@ -269,7 +269,7 @@ enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
 // Row padding of the x pass's LDS tile (complex elements).  Lanes run over the NB transforms first, then over consecutive positions:
 // element (b, pos) starts at bank group (pad * b + pos) mod 16, and a 64-lane 16-byte access is conflict-free when each of the 16
 // groups gets 4 lanes, i.e. when the NB ranges [pad * b, pad * b + 64/NB) tile the line: pad ~ 64 / NB.
-constexpr int x_ld_pad(int NB) { return NB == 12 ? 5 : (NB == 6 ? 11 : 1); }
+constexpr int x_ld_pad(int NB) { return NB == 12 ? 5 : (NB == 6 ? 10 : 1); }
 
 // spectra of the x pass: field groups A / B are read from in* and written to out* (same layout; in == out means in place)
 struct XSpec {
@@ -279,9 +279,9 @@ struct XSpec {
     cplx* outB;
 };
 
-template <int L, int MODE, int T, int NT>
+template <int L, int MODE, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
-                                       cplx* buf, const cplx* tw, const size_t i0, const int tid) {
+                                       cplx* buf, const TW tw, const size_t i0, const int tid) {
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
@@ -415,20 +415,24 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 // tiles of a line are given to workgroups b, b+8, ..., which the dispatcher places on the same XCD at about the same time: the
 // rest of every line is then served by that XCD's L2 instead of being fetched from HBM again (speed only, never correctness).
 template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = tiles per 128-byte line of the spectra (0/1: no remapping)
-__global__ __launch_bounds__(NT) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
     __shared__ cplx buf[NB * (L + x_ld_pad(NB))];
-    __shared__ cplx tw[L];
+    // G > 192: half twiddle table — with the full one (6 KB at G = 384) the tile fits only three times into a CU's LDS instead of four
+    constexpr bool HALF = (L > 192);
+    constexpr int NTW = HALF ? L / 2 : L;
+    __shared__ cplx tw_s[NTW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    for (int i = tid; i < NTW; i += NT) tw_s[i] = tw_g[i];
     __syncthreads();
     size_t tile = blockIdx.x;
     if (PAIRED > 1 && blockIdx.x < (gridDim.x / (8 * PAIRED)) * (8 * PAIRED)) {
         const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);
         tile = (size_t)q * (8 * PAIRED) + PAIRED * (r % 8) + r / 8;
     }
-    x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, tw, tile * T, tid);
+    if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
+    else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, tile * T, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
