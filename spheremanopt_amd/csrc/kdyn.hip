@@ -174,9 +174,15 @@ enum { ZF_PLAIN = 0, ZF_FWD_UPDATE = 1, ZF_ADJ_UPDATE = 2, ZF_NU = 3 };
 
 // ZF_PLAIN: truncated spectrum;  ZF_FWD_UPDATE: B^_{n+1};  ZF_ADJ_UPDATE: G^ update with forcing F1 = F[(curl G) x U] (minus 2 B_f if
 // integrated);  ZF_NU: nu^ = -dt P(F[sum_n (curl G_n) x B_n]) from the accumulated product (see the fused adjoint x pass)
-template <int L, int MODE, int NBT, int NT>
-__global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA, cplx* out0, const cplx* state0 /* may alias out0 */,
-                                                   const cplx* snap, const cplx* __restrict__ tw_g, Geom g, double scale, int integrated) {
+// NEXT: the z pass that opens the following time step works on the very rows this kernel has just updated, so it can run here, on the
+// tile, instead of re-reading the new state in a kernel of its own: NX_PLAIN = inverse z pass of the new state (forward solve),
+// NX_CURL = inverse z pass of i k x (new state) (adjoint solve).  The result goes where the input came from (the z-side exchange
+// buffer, same layout), which is safe because a workgroup owns its rows.
+enum { NX_NONE = 0, NX_PLAIN = 1, NX_CURL = 2 };
+template <int L, int MODE, int NEXT, int NBT, int NT>
+__global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, const cplx* state0 /* may alias out0 */,
+                                                   const cplx* snap, const cplx* __restrict__ tw_g, Geom g, double scale, int integrated,
+                                                   cplx* next_out /* may alias inA */) {
     constexpr int NB = 3 * NBT;
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
@@ -240,6 +246,26 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* __restrict__ inA,
             cnab_mode(k, k2, alpha, beta, V0, E, V1);
         }
         for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
+        if (NEXT != NX_NONE) {                          // the new state (or its curl) replaces the spectrum in the tile
+            for (int c = 0; c < 3; ++c) {
+                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                buf[(tt * 3 + c) * L + pos] = (NEXT == NX_PLAIN) ? V1[c]
+                    : mul_i(mk(k[c1] * V1[c2].re - k[c2] * V1[c1].re, k[c1] * V1[c2].im - k[c2] * V1[c1].im));
+            }
+        }
+    }
+    if (NEXT != NX_NONE) {
+        const int gap = g.G - g.m;                      // zero padding between the positive and the negative wavenumbers
+        for (int t = tid; t < NB * gap; t += NT) {
+            const int b = t / gap, q = t - b * gap;
+            buf[b * L + g.kmax + 1 + q] = mk(0, 0);
+        }
+        __syncthreads();
+        fft_inplace<L, true, NB, NT, false, true, false>(buf, L, tw, tid, [&](int b, int pos) { return buf[b * L + pos]; },
+                                                         [&](int b, int pos, cplx v) {
+                                                             const int c = b % 3, tt = b / 3, rt = rt0 + tt;
+                                                             if (rt < nrt) next_out[zs_off(c, rt, pos, g)] = v;
+                                                         });
     }
 }
 
@@ -566,7 +592,7 @@ public:
         }
         K = k; g.Gzl = Gzc; tzc = tzb / K; ngc = n_grid / K;
         g.typ = (size_t)g.G * Gzc + (K <= TY_KMAX ? ty_pad : 0); fldc = (size_t)3 * g.a * g.typ;
-        have_forward = false;
+        have_forward = false; zs_ready_fwd = zs_ready_adj = -1;
         return SMO_OK;
     }
 
@@ -589,6 +615,7 @@ public:
         // One 128-byte line of padding per (component, kx) plane of Ty.  The x pass gathers 3a runs per tile, one per plane; with the
         // natural stride 16*G*Gzl (a multiple of 64 KB at every supported size) they all fall on the same HBM channel: measured
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
+        { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
         if (ty_pad % 8 != 0) { set_error("KDYN: SMO_KD_TYPAD must be a multiple of 8 elements (one 128-byte line)"); return SMO_ERR_ARG; }
         g.typ = (size_t)g.G * g.Gzl + ty_pad;
@@ -641,8 +668,9 @@ public:
         k_yf = timing.add_class("kd_y_pass<fwd>", 3 * (S1 + S2));
         k_xf = timing.add_class("kd_x_pass<fused_fwd>", 3 * (2 * (S2 + S3) + 3 * S3));           // 3 c2r + 3 r2c passes + pointwise (read B,U write EMF)
         k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3));           // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2; the running sum's read is not counted)
-        k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0);         // 3 z passes + step (read B,N; write B, snapshot)
-        k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0);         // F1 only: F2 is summed on the grid side (nu_B / nu_C)
+        const double nxt = fuse_next ? 3 * (S0 + S1) : 0.0;                                     // + the next step's inverse z pass, run on the same tile
+        k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0 + nxt);   // 3 z passes + step (read B,N; write B, snapshot)
+        k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0 + nxt);   // F1 only: F2 is summed on the grid side (nu_B / nu_C)
         k_misc = timing.add_class("kd_misc(setup/terminal/energy/grid io)", 0);
         return SMO_OK;
     }
@@ -682,6 +710,7 @@ public:
     // coefficients -> field group `f` (of `nf`) of the z-side exchange buffer
     int z_inverse(int mode, const cplx* in, int f, int nf) {
         const Geom g = geom(nf);
+        zs_ready_fwd = zs_ready_adj = -1;
         cplx* out = zs + (size_t)f * tzc;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
@@ -697,6 +726,7 @@ public:
     // y pass between field group `f` (of `nf`) of chunk `k` of the y-side exchange buffer and (that chunk of) one field group of Ty at `ty`
     int y_pass(bool inv, int f, int nf, cplx* ty, int k = 0) {
         const Geom q = geom(nf, k);
+        if (!inv && ys == zs) zs_ready_fwd = zs_ready_adj = -1;      // one GPU: the y pass writes the buffer the z pass reads
         cplx* ex = ys + (size_t)k * q.cblk + (size_t)f * tzc;
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
@@ -741,8 +771,9 @@ public:
             return SMO_OK;
         });
     }
-    // z-side exchange buffer (one field group) -> coefficients / time-step update
-    int z_forward(int mode, cplx* out0, const cplx* state0, const cplx* snp) {
+    // z-side exchange buffer (one field group) -> coefficients / time-step update [-> z-side buffer again: inverse z pass of the new
+    // state, see NX_*]
+    int z_forward(int mode, cplx* out0, const cplx* state0, const cplx* snp, int next = NX_NONE) {
         const Geom g = geom(1);
         const double scale = 1.0 / ((double)g.G * g.G * g.G);
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
@@ -753,12 +784,12 @@ public:
             ScopedTimer t(timing, k, stream);
             const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
             const dim3 grid(nwg), block(S::ZNT);
-            switch (mode) {
-                case ZF_PLAIN: hipLaunchKernelGGL((kd_z_forward<L, ZF_PLAIN, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
-                case ZF_FWD_UPDATE: hipLaunchKernelGGL((kd_z_forward<L, ZF_FWD_UPDATE, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
-                case ZF_ADJ_UPDATE: hipLaunchKernelGGL((kd_z_forward<L, ZF_ADJ_UPDATE, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
-                default: hipLaunchKernelGGL((kd_z_forward<L, ZF_NU, S::ZNBT, S::ZNT>), grid, block, 0, stream, zs, out0, state0, snp, d_tw, g, scale, integ); break;
-            }
+#define SMO_ZF(MODE_, NEXT_) hipLaunchKernelGGL((kd_z_forward<L, MODE_, NEXT_, S::ZNBT, S::ZNT>), grid, block, 0, stream, (const cplx*)zs, out0, state0, snp, d_tw, g, scale, integ, zs)
+            if (mode == ZF_PLAIN) SMO_ZF(ZF_PLAIN, NX_NONE);
+            else if (mode == ZF_NU) SMO_ZF(ZF_NU, NX_NONE);
+            else if (mode == ZF_FWD_UPDATE) { if (next == NX_PLAIN) SMO_ZF(ZF_FWD_UPDATE, NX_PLAIN); else SMO_ZF(ZF_FWD_UPDATE, NX_NONE); }
+            else { if (next == NX_CURL) SMO_ZF(ZF_ADJ_UPDATE, NX_CURL); else SMO_ZF(ZF_ADJ_UPDATE, NX_NONE); }
+#undef SMO_ZF
             return SMO_OK;
         });
     }
@@ -771,25 +802,42 @@ public:
     cplx* tyslot(int n, int k = 0) { return d_tystack + (size_t)n * fld + (size_t)k * fldc; }
     cplx* tyw(int f, int k) { return d_ty + (size_t)f * fld + (size_t)k * fldc; }       // work copy of Ty: field group f, chunk k
     bool have_ty(int n) const { return d_tystack != nullptr && n >= 0 && n < cfg.n_iters; }
-    int fwd_A(int n) { return z_inverse(ZI_PLAIN, snap(n), 0, 1); }
+    // zs_ready_*: the z-side buffer already holds the inverse z pass of snapshot n / of curl(G^) for adjoint index idx, left there by
+    // the update kernel of the step before (NX_*); every other writer of the z-side buffer clears them.
+    int zs_ready_fwd = -1, zs_ready_adj = -1;
+    bool adj_cont = false;
+    bool fuse_next = true;                     // SMO_KD_FUSE_NEXT=0: separate kernels (ablation)
+    int fwd_A(int n) {
+        if (zs_ready_fwd == n) { zs_ready_fwd = -1; return SMO_OK; }
+        return z_inverse(ZI_PLAIN, snap(n), 0, 1);
+    }
     int fwd_B(int n, int k) {
         cplx* ty = have_ty(n) ? tyslot(n, k) : tyw(0, k);
         SMO_TRY(y_pass(true, 0, 1, ty, k));
         SMO_TRY(x_pass(X_FUSED_FWD, k, nullptr, nullptr, ty));
         return y_pass(false, 0, 1, tyw(0, k), k);
     }
-    int fwd_C(int n) { return z_forward(ZF_FWD_UPDATE, snap(n + 1), snap(n), nullptr); }
+    int fwd_C(int n) {
+        const bool fuse = fuse_next && n + 1 < cfg.n_iters;
+        SMO_TRY(z_forward(ZF_FWD_UPDATE, snap(n + 1), snap(n), nullptr, fuse ? NX_PLAIN : NX_NONE));
+        zs_ready_adj = -1;
+        zs_ready_fwd = fuse ? n + 1 : -1;
+        return SMO_OK;
+    }
     int adj_init(int adjoint_type) {
         ScopedTimer t(timing, k_misc, stream);
         hipLaunchKernelGGL(kd_terminal, dim3(1024), dim3(256), 0, stream, snap(cfg.n_iters), d_G, d_nu, g, cfg.cost == SMO_COST_INTEGRATED ? 1 : 0,
                            adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
         SMO_HIP(hipMemsetAsync(d_acc, 0, fld * sizeof(cplx), stream));
+        adj_cont = adjoint_type == SMO_ADJ_CONTINUOUS;
+        zs_ready_fwd = zs_ready_adj = -1;
         return SMO_OK;
     }
     // inverse side of an adjoint step carries omega only (1 field group) when B_f was kept by the forward solve, else omega and B^_idx
     int adj_groups(int idx) const { return have_ty(idx) ? 1 : 2; }
     int adj_A(int idx) {
         const int nf = adj_groups(idx);
+        if (zs_ready_adj == idx && nf == 1) { zs_ready_adj = -1; return SMO_OK; }
         SMO_TRY(z_inverse(ZI_CURL, d_G, 0, nf));
         return nf == 2 ? z_inverse(ZI_PLAIN, snap(idx), 1, 2) : SMO_OK;
     }
@@ -800,7 +848,16 @@ public:
         SMO_TRY(x_pass(X_FUSED_ADJ, k, nullptr, nullptr, nullptr, nf == 1 ? tyslot(idx, k) : nullptr));
         return y_pass(false, 0, 1, tyw(0, k), k);
     }
-    int adj_C(int idx) { return z_forward(ZF_ADJ_UPDATE, d_G, d_G, snap(idx)); }
+    int adj_C(int idx) {
+        // the following adjoint step (index idx - 1) starts with the inverse z pass of curl(G^): fused when that step sends one field
+        // group (same buffer layout as this kernel's input) and exists at all (the continuous sweep ends at index 1, the discrete at 0)
+        const int nxt = idx - 1;
+        const bool fuse = fuse_next && nxt >= (adj_cont ? 1 : 0) && adj_groups(nxt) == 1;
+        SMO_TRY(z_forward(ZF_ADJ_UPDATE, d_G, d_G, snap(idx), fuse ? NX_CURL : NX_NONE));
+        zs_ready_fwd = -1;
+        zs_ready_adj = fuse ? nxt : -1;
+        return SMO_OK;
+    }
     // The nu^ recursion of the reference, nu <- R nu - dt P F2_n (R = I - 2 k k^T/k^2, nu_N = 0), never leaves the solenoidal subspace,
     // where R is the identity: nu_0 = -dt P sum_n F2_n exactly.  The fused adjoint x pass therefore adds its second product
     // (curl G_n) x B_n, already transformed along x, to a running sum on the grid side (d_acc, the layout of Ty); the y and z passes,
@@ -921,7 +978,7 @@ public:
         if (op == SMO_KD_SET_CHUNKS) return set_chunks(i0);
         if (op == SMO_KD_SET_BUFFERS) {
             if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
-            zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1);
+            zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1); zs_ready_fwd = zs_ready_adj = -1;
             return SMO_OK;
         }
         if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(tzb * cfg.world); return SMO_OK; }
