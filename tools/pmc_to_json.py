@@ -11,7 +11,7 @@ from collections import defaultdict
 
 XMODE = {0: "kd_misc(x to grid)", 1: "kd_misc(x from grid)", 2: "kd_x_pass<fused_fwd>", 3: "kd_x_pass<fused_adj>"}
 ZI = {0: "kd_z_inverse", 1: "kd_z_inverse<curl>", 2: "kd_misc(z inverse scaled)"}
-ZF = {0: "kd_misc(z forward plain)", 1: "kd_z_forward<fwd_update>", 2: "kd_z_forward<adj_update>"}
+ZF = {0: "kd_misc(z forward plain)", 1: "kd_z_forward<fwd_update>", 2: "kd_z_forward<adj_update>", 3: "kd_misc(z forward nu)"}
 
 
 def classify(name):
@@ -23,8 +23,9 @@ def classify(name):
         return XMODE[int(args[1])]
     if base == "kd_z_inverse":
         return ZI[int(args[1])]
-    if base == "kd_z_forward":
-        return ZF[int(args[1])]
+    if base == "kd_z_forward":          # template arguments: L, MODE, NEXT, ...; the last step of a solve runs without the fused next pass
+        mode, nxt = int(args[1]), int(args[2])
+        return ZF[mode] if (mode in (0, 3) or nxt != 0) else "kd_misc(z forward update, last step)"
     if base == "kd_y_pass":
         return "kd_y_pass<inv>" if args[1] == "true" else "kd_y_pass<fwd>"
     return base
