@@ -38,7 +38,7 @@ s.forward([Bl, Ul]); s.adjoint("Discrete", out)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 J1 = s.forward([Bl, Ul]); s.adjoint("Discrete", out)
 torch.cuda.synchronize(); t_slab = time.perf_counter() - t0
-nex = (4 + s.adj_groups) * n
+nex = (3 + s.adj_groups) * n          # fwd 1+1, adj (1 or 2)+1 field-group exchanges per step
 print(json.dumps({"npts": N, "n_iters": n, "monolithic_s": t_mono, "slab_loop_one_rank_s": t_slab, "exchanges": nex,
                   "overhead_us_per_exchange": 1e6 * (t_slab - t_mono) / nex, "bytes_per_exchange_MB": s.elems * 16 / 1e6,
                   "J_equal": J0 == J1}))
