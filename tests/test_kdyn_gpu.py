@@ -212,3 +212,34 @@ def test_y_side_stack_is_bit_identical(monkeypatch):
     for adj in ("Discrete", "Continuous"):
         a, b = res[("1", adj)], res[("0", adj)]
         assert a[0] == b[0] and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+
+
+@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYPAD", "24")])
+@pytest.mark.parametrize("N", [32, 48])
+def test_layout_and_fusion_knobs_are_bit_identical(monkeypatch, knob, off, N):
+    """Two pure performance devices must not change a single bit: (i) the update kernels run the next step's inverse z pass on the tile
+    they have just updated, in place in the exchange buffer (SMO_KD_FUSE_NEXT=0: separate kernels); (ii) the Ty planes are padded by one
+    128-byte line against HBM channel conflicts (SMO_KD_TYPAD: other paddings / none).  Both adjoint types, with and without the
+    grid-side stack (without it the adjoint sends two field groups and the fused pass must step aside)."""
+    n = 5
+    B, U = _fields(3 * N // 2, dirty=True)
+    res = {}
+    for stack in ("1", "0"):
+        monkeypatch.setenv("SMO_KD_TYSTACK", stack)
+        for val in (None, off):
+            if val is None:
+                monkeypatch.delenv(knob, raising=False)
+            else:
+                monkeypatch.setenv(knob, val)
+            dom = kdyn.KDynDomain(N)
+            buf = kdyn.GEN_BUFFER(N, dom, n)
+            for adj in ("Discrete", "Continuous"):
+                args = [dom, 1., 1e-3, n, n, buf, "Integrated", adj]
+                J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+                g = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+                res[(stack, val, adj)] = (J, g, np.stack([buf[k][:, :, :, i] for k in ("A_fwd", "B_fwd", "C_fwd") for i in range(n + 1)]))
+            dom.drop_contexts()
+        for adj in ("Discrete", "Continuous"):
+            a, b = res[(stack, None, adj)], res[(stack, off, adj)]
+            assert a[0] == b[0] and np.array_equal(a[2], b[2]), (stack, adj)
+            assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]), (stack, adj)
