@@ -214,4 +214,29 @@ __device__ __forceinline__ void fft_inplace(cplx* buf, int LD, TW tw, int tid, L
     InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN, pre);
 }
 
+// All stages but the last one (LDS -> LDS, a barrier after each): for callers that fuse their own work into the last stage, whose
+// butterfly j reads and writes the same positions j + (L/R) k — thread-local, so it needs no barrier before what follows on those values.
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST> struct InplaceHead {
+    template <class TW>
+    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, TW tw) {
+        constexpr int R = radix_of(N);
+        if constexpr (N / R > 1) {
+            auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
+            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+            __syncthreads();
+            InplaceHead<L, N / R, S * R, INV, NB, NT, BFAST>::run(buf, LD, tid, tw);
+        }
+    }
+};
+template <int L> constexpr int last_radix() { int n = L; while (n / radix_of(n) > 1) n /= radix_of(n); return n; }
+
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, class TW, class Load0>
+__device__ __forceinline__ void fft_inplace_head(cplx* buf, int LD, TW tw, int tid, Load0 ld0) {
+    constexpr int R0 = radix_of(L);
+    static_assert(L / R0 > 1, "transform needs at least two stages");
+    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+    __syncthreads();
+    InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST>::run(buf, LD, tid, tw);
+}
+
 }  // namespace smo

@@ -377,52 +377,50 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     if (MODE == X_FROM_GRID) {
         fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
     } else {
-        // pointwise products on the grid; item = (x, p), p fastest.  The velocity at a thread's items is requested before the last
-        // stage of the inverse transform and arrives while that stage runs.
-        // (Forward pass up to G = 288 only: measured 112 -> 103 us at G = 192; at G = 384 the extra registers cost a wave per SIMD
-        // (1059 -> 1148 us), and the adjoint pass, which also waits for B_f from the LDS, does not change.)
-        constexpr bool PREF = (MODE == X_FUSED_FWD && L <= 288);
-        constexpr int UCNT = (HP * L + NT - 1) / NT;
-        cplx Ug[PREF ? UCNT : 1][3];
-        auto load_U = [&](int i) {
-            const int t = tid + i * NT, x = t / HP, p = t - x * HP;
-            if (t < HP * L && line_ok(p))
-                for (int c = 0; c < 3; ++c) {
-                    const double* q = gridU + u_off(c, x, i0 + 2 * p, g);
-                    Ug[PREF ? i : 0][c] = mk(q[0], q[1]);
-                }
-        };
-        fft_inplace<L, true, NB, NT, true, false, true>(buf, LD, tw, tid, ld_spec, st_buf, [&]() {
-            if (PREF) {
+        // The last stage of the inverse transform is a radix-3 butterfly over x = j, j + a, j + 2a (a = L/3) that reads and writes the
+        // same three positions.  A thread that runs it for every component of one line pair therefore holds the whole vectors at those
+        // grid points in registers and forms the cross product(s) right there: no barrier and no LDS round trip between transform and
+        // product.  The velocity is requested first and arrives while the butterflies run.  Item = (j, p), p fastest.
+        static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
+        fft_inplace_head<L, true, NB, NT, true, false>(buf, LD, tw, tid, ld_spec);
+        constexpr int S3 = L / 3;
+        constexpr int ICNT = (HP * S3 + NT - 1) / NT;
+#pragma unroll 1
+        for (int i = 0; i < ICNT; ++i) {
+            const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+            if (t >= HP * S3 || !line_ok(p)) continue;
+            cplx U[3][3], W[3][3];                  // [x = j + k a][component]; .re / .im = the two real lines of the pair
 #pragma unroll
-                for (int i = 0; i < UCNT; ++i) load_U(i);
-            }
-        });
-        __syncthreads();
+            for (int k = 0; k < 3; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g);
+                    U[k][c] = mk(q[0], q[1]);
+                }
+            auto last_stage = [&](int f, cplx (&out)[3][3]) {
 #pragma unroll
-        for (int i = 0; i < UCNT; ++i) {
-            const int t = tid + i * NT, x = t / HP, p = t - x * HP;
-            if (t >= HP * L || !line_ok(p)) continue;
-            cplx A[3], U[3];                        // .re / .im = the two real lines of the pair
-            if (!PREF) load_U(i);
-            for (int c = 0; c < 3; ++c) {
-                A[c] = buf[(c * HP + p) * LD + x];
-                U[c] = Ug[PREF ? i : 0][c];
-            }
-            if (MODE == X_FUSED_FWD) {              // EMF = U x B
                 for (int c = 0; c < 3; ++c) {
-                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                    buf[(c * HP + p) * LD + x] = mk(U[c1].re * A[c2].re - U[c2].re * A[c1].re, U[c1].im * A[c2].im - U[c2].im * A[c1].im);
+                    cplx v[3];
+                    for (int k = 0; k < 3; ++k) v[k] = buf[((f * 3 + c) * HP + p) * LD + j + S3 * k];
+                    Butterfly<3, true>::run(v);
+                    for (int k = 0; k < 3; ++k) out[k][c] = v[k];
                 }
-            } else {                                // F1 = omega x U ;  F2' = omega x B_f
-                cplx Bf[3];
-                for (int c = 0; c < 3; ++c) Bf[c] = buf[((3 + c) * HP + p) * LD + x];
-                for (int c = 0; c < 3; ++c) {
-                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                    buf[(c * HP + p) * LD + x] = mk(A[c1].re * U[c2].re - A[c2].re * U[c1].re, A[c1].im * U[c2].im - A[c2].im * U[c1].im);
-                    buf[((3 + c) * HP + p) * LD + x] =
-                        mk(A[c1].re * Bf[c2].re - A[c2].re * Bf[c1].re, A[c1].im * Bf[c2].im - A[c2].im * Bf[c1].im);
-                }
+            };
+            auto cross_to = [&](int f, const cplx (&X)[3][3], const cplx (&Y)[3][3]) {       // field group f <- X x Y
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    for (int c = 0; c < 3; ++c) {
+                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                        buf[((f * 3 + c) * HP + p) * LD + j + S3 * k] =
+                            mk(X[k][c1].re * Y[k][c2].re - X[k][c2].re * Y[k][c1].re, X[k][c1].im * Y[k][c2].im - X[k][c2].im * Y[k][c1].im);
+                    }
+            };
+            last_stage(0, W);
+            if (MODE == X_FUSED_FWD) {
+                cross_to(0, U, W);                  // EMF = U x B
+            } else {
+                cross_to(0, W, U);                  // F1 = omega x U
+                last_stage(1, U);                   // B_f takes the velocity's registers
+                cross_to(1, W, U);                  // F2' = omega x B_f
             }
         }
         __syncthreads();
