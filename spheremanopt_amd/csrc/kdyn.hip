@@ -377,15 +377,37 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     if (MODE == X_FROM_GRID) {
         fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
     } else {
-        // The last stage of the inverse transform is a radix-3 butterfly over x = j, j + a, j + 2a (a = L/3) that reads and writes the
-        // same three positions.  A thread that runs it for every component of one line pair therefore holds the whole vectors at those
-        // grid points in registers and forms the cross product(s) right there: no barrier and no LDS round trip between transform and
-        // product.  The velocity is requested first and arrives while the butterflies run.  Item = (j, p), p fastest.
+        // The middle of the pass runs in registers.  G = 3N/2, so the inverse transform (radix order 4..4[2]3) ENDS with a radix-3
+        // butterfly over x = j, j + a, j + 2a (a = L/3), and the forward transform, taken in the order 3 4..4[2], BEGINS with a radix-3
+        // butterfly over the same three points.  A thread that owns (j, line pair p) for every component therefore does: last inverse
+        // butterflies -> cross product(s) at its three grid points -> first forward butterflies (+ twiddles), touching the LDS once
+        // (read j + k a, write 3 j + k) with one barrier in between, instead of three round trips and three barriers.  The velocity is
+        // requested before that barrier and arrives while the others finish reading.  Item = (j, p), p fastest.
         static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
         fft_inplace_head<L, true, NB, NT, true, false>(buf, LD, tw, tid, ld_spec);
         constexpr int S3 = L / 3;
         constexpr int ICNT = (HP * S3 + NT - 1) / NT;
-#pragma unroll 1
+        cplx Win[ICNT][NF][3][3];                   // [item][field group][component][k]: inputs of the last inverse stage
+        cplx U0[3][3];                              // velocity at the first item's points, [k][component]
+#pragma unroll
+        for (int i = 0; i < ICNT; ++i) {
+            const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+            if (t < HP * S3 && line_ok(p)) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    for (int c = 0; c < 3; ++c)
+                        for (int k = 0; k < 3; ++k) Win[i][f][c][k] = buf[((f * 3 + c) * HP + p) * LD + j + S3 * k];
+                if (i == 0)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        for (int c = 0; c < 3; ++c) {
+                            const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g);
+                            U0[k][c] = mk(q[0], q[1]);
+                        }
+            }
+        }
+        __syncthreads();
+#pragma unroll
         for (int i = 0; i < ICNT; ++i) {
             const int t = tid + i * NT, j = t / HP, p = t - j * HP;
             if (t >= HP * S3 || !line_ok(p)) continue;
@@ -393,26 +415,31 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 for (int c = 0; c < 3; ++c) {
-                    const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g);
-                    U[k][c] = mk(q[0], q[1]);
+                    if (i == 0) U[k][c] = U0[k][c];
+                    else { const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g); U[k][c] = mk(q[0], q[1]); }
                 }
             auto last_stage = [&](int f, cplx (&out)[3][3]) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     cplx v[3];
-                    for (int k = 0; k < 3; ++k) v[k] = buf[((f * 3 + c) * HP + p) * LD + j + S3 * k];
+                    for (int k = 0; k < 3; ++k) v[k] = Win[i][f][c][k];
                     Butterfly<3, true>::run(v);
                     for (int k = 0; k < 3; ++k) out[k][c] = v[k];
                 }
             };
-            auto cross_to = [&](int f, const cplx (&X)[3][3], const cplx (&Y)[3][3]) {       // field group f <- X x Y
+            auto cross_to = [&](int f, const cplx (&X)[3][3], const cplx (&Y)[3][3]) {       // field group f <- first forward stage of X x Y
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    for (int c = 0; c < 3; ++c) {
-                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                        buf[((f * 3 + c) * HP + p) * LD + j + S3 * k] =
-                            mk(X[k][c1].re * Y[k][c2].re - X[k][c2].re * Y[k][c1].re, X[k][c1].im * Y[k][c2].im - X[k][c2].im * Y[k][c1].im);
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                    cplx v[3];
+                    for (int k = 0; k < 3; ++k)
+                        v[k] = mk(X[k][c1].re * Y[k][c2].re - X[k][c2].re * Y[k][c1].re, X[k][c1].im * Y[k][c2].im - X[k][c2].im * Y[k][c1].im);
+                    Butterfly<3, false>::run(v);
+                    cplx* row = buf + ((f * 3 + c) * HP + p) * LD + 3 * j;
+                    row[0] = v[0];
+                    row[1] = twmul<false>(v[1], tw[j]);
+                    row[2] = twmul<false>(v[2], tw[2 * j]);
+                }
             };
             last_stage(0, W);
             if (MODE == X_FUSED_FWD) {
@@ -424,8 +451,9 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
             }
         }
         __syncthreads();
-        // group B of the adjoint pass is a running sum: its old values are requested before the last stage of the transform
-        fft_inplace<L, false, NB, NT, true, true, true>(buf, LD, tw, tid, [&](int b, int pos) { return buf[b * LD + pos]; }, st_buf, [&]() {
+        // remaining forward stages (sub-length a, stride 3); group B of the adjoint pass is a running sum: its old values are requested
+        // before the last stage
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run(buf, LD, tid, tw, st_buf, [&]() {
             if (ACC) {
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
