@@ -8,18 +8,21 @@
 // Data layout in HBM (N = npts, a = N/2 kx modes, m = N-1 ky/kz modes, G = 3N/2 grid points per axis):
 //   coefficient fields  C [3][a][m][m]   complex128, kz fastest      (snapshot stack: [n][3][a][m][m])
 //   after the z pass    Tz[3][a][m][G]   complex128, z fastest       (slab exchange layout: [peer][field group][3][a/W][m][G/W])
-//   after the y pass    Ty[3][a][G][G]   complex128, z fastest       (slabs: [3][a][G][G/W], all kx, local z planes)
+//   after the y pass    Ty[3][a][G*G+8]  complex128, z fastest       (slabs: [3][a][G*G/W+8], all kx, local z planes; the 8 elements of
+//                                                                     padding keep a tile's 3a runs off one HBM channel)
 //   grid fields         U [3][G][G][G]   float64,    z fastest       (= the reference's flat X vectors; slabs: [3][G][G][G/W])
 // Slab decomposition (W ranks): coefficient space is split over kx, grid space over z.  The z passes run on the kx slab, the y
 // and x passes on the z slab, and the exchange sits between the z and the y pass, where the data is smallest (16*a*m*G bytes per
 // component instead of 16*a*G*G after the y pass).  With W = 1 the "exchange buffer" is simply Tz.
 // One 3-D transform = three 1-D passes (z contiguous, y strided, x strided).  Every pass reads HBM in its first
 // Stockham stage (zero padding folded into the load) and writes HBM in its last (truncation folded into the store).
-// Fusions per time step:
-//   x pass  : c2r (two real lines per complex FFT) -> cross product with U (and B_f) on the grid -> r2c, one kernel
+// Fusions per time step (4 kernels per forward step, 4 per adjoint step):
+//   x pass  : c2r (two real lines per complex FFT) -> cross product with U (and B_f) on the grid -> r2c, one kernel; the last
+//             inverse stage, the products and the first forward stage run in registers
 //   z pass  : forward z transform -> i k x (.) -> Leray projection -> CNAB1 update -> next state written straight
-//             into the snapshot stack (the stack IS the state; no copy)
-//   curl    : omega = i k x G is formed while loading the z pass of the adjoint
+//             into the snapshot stack (the stack IS the state; no copy) -> inverse z transform of that state (adjoint: of its
+//             curl) for the next step, on the same tile
+//   nu      : the adjoint's second product is summed over the steps on the grid side (x-transformed) and transformed once
 #include <algorithm>
 
 #include "fft_lds.hpp"

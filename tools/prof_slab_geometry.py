@@ -51,7 +51,8 @@ def run(N, W, n_iters, keep):
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     n_iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    for W in (1, 2, 4, 8):
+    Ws = [int(w) for w in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 4, 8)
+    for W in Ws:
         r = run(N, W, n_iters, keep=True)
         print(json.dumps(r), flush=True)
         torch.cuda.empty_cache()
