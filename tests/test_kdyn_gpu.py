@@ -30,7 +30,7 @@ def _fields(G, dirty=False):
 
 
 @pytest.mark.parametrize("N,n,dt,dirty", [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True),
-                                          (96, 1, 1e-3, False)])
+                                          (96, 1, 1e-3, False), (128, 2, 1e-3, False)])
 @pytest.mark.parametrize("cost", ["Final", "Integrated"])
 @pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
 def test_forward_adjoint_vs_oracle(N, n, dt, dirty, cost, adj):
