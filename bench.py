@@ -251,8 +251,8 @@ def bench_kdyn_slab(a, torch, rank, world):
            "slab_J_matches_single_gpu": bool(abs(J - float(J_single.item())) <= 1e-9 * abs(float(J_single.item()))),
            "J_single_gpu": float(J_single.item()),
            "parallelism": "slab x%d (kx / z decomposition, RCCL all-to-all between the z and y passes, %d field-group exchanges per "
-                          "step pair, %d pipelined z chunks)" % (world, 4 + s.adj_groups, s.K),
-           "exchange_MB_sent_per_gpu_per_step_pair": (4 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
+                          "step pair, %d pipelined z chunks)" % (world, 3 + s.adj_groups, s.K),
+           "exchange_MB_sent_per_gpu_per_step_pair": (3 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
            "grid_states_kept_GB_per_gpu": s.ops.ctx.get(1) / 1e9}
     # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)
     big = int(os.environ.get("SMO_BENCH_SLAB_EXTRA_NPTS", "256"))
@@ -270,7 +270,7 @@ def bench_kdyn_slab(a, torch, rank, world):
             cfg["config_256"] = {"workload": "Kinematic dynamo 3D Fourier %d^3 slab-decomposed across %d GPUs, T=%g, dt=%g" % (big, world, dt * n_iters, dt),
                                  "ms_per_gradient": 1e3 * el2, "gradient_evals_per_s": 1.0 / el2, "steps": 1, "warmup": 0, "J": J2,
                                  "stack_GB_per_gpu": s2.ops.ctx.stack_bytes / 1e9,
-                                 "exchange_MB_sent_per_gpu_per_step_pair": (4 + s2.adj_groups) * s2.elems * 16 / 1e6 * (world - 1) / world}
+                                 "exchange_MB_sent_per_gpu_per_step_pair": (3 + s2.adj_groups) * s2.elems * 16 / 1e6 * (world - 1) / world}
             del s2
         except Exception as e:                       # never lose the main line because of the extra
             cfg["config_256"] = {"error": repr(e)}
