@@ -115,6 +115,23 @@ class SlabKDyn:
             with torch.cuda.device(self.dev):
                 self.stream = torch.cuda.Stream()            # kernels AND collectives are ordered on this stream
             ops = HipOps(Npts, Rm, dt, N_ITERS, Cost_function, device, self.rank, self.world, stream=self.stream.cuda_stream)
+            if self.world > 1:
+                # whether the grid-side states are kept decides how many field groups an adjoint step exchanges: every rank takes that
+                # decision from its own free HBM, so agree on it (all or none) before the first collective of a solve could mismatch
+                staged = _dist().get_backend() == "gloo"
+                mine = torch.tensor([1.0 if ops.keeps_grid_states else 0.0], dtype=torch.float64, device="cpu" if staged else self.dev)
+                _dist().all_reduce(mine, op=_dist().ReduceOp.MIN)
+                if ops.keeps_grid_states and float(mine.item()) < 0.5:
+                    ops.ctx.close()
+                    prev = os.environ.get("SMO_KD_TYSTACK")
+                    os.environ["SMO_KD_TYSTACK"] = "0"
+                    try:
+                        ops = HipOps(Npts, Rm, dt, N_ITERS, Cost_function, device, self.rank, self.world, stream=self.stream.cuda_stream)
+                    finally:
+                        if prev is None:
+                            del os.environ["SMO_KD_TYSTACK"]
+                        else:
+                            os.environ["SMO_KD_TYSTACK"] = prev
         else:
             self.dev = torch.device(getattr(ops, "device", "cpu"))
         self.ops = ops
