@@ -415,6 +415,18 @@ def main():
             secondary.append({"workload": cf["workload"], "value": st * units / e2, "unit": "gradient evals/s", "ms_per_step": 1e3 * e2 / st,
                               "us_per_time_step": (1e6 * e2 / st / (2 * cf["n_iters"])) if fn is bench_pois else rf["avg_launch_ms"] * 1e3 / cf["n_iters"],
                               "steps": st, "warmup": wm})
+        # BASELINE configs[4]'s grid on this ONE GPU (windowed checkpoints): the 1-GPU end of the 256^3 strong-scaling series whose
+        # N-GPU points the N > 1 runs report under the same key
+        if wl == "kdyn" and a.npts is None and a.iters is None:
+            try:
+                torch.cuda.empty_cache()
+                b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": 1, "warmup": 0, "no_cpu_baseline": True})
+                st, _, e2, _, _, cf, _ = bench_kdyn(b, torch, rank, world)
+                cfg["config_256"] = {"workload": cf["workload"] + " on 1 GPU", "ms_per_gradient": 1e3 * e2 / st, "gradient_evals_per_s": st / e2,
+                                     "steps": st, "warmup": 0, "J": cf["J"], "stack_GB_per_gpu": cf["stack_GB"],
+                                     "checkpoint_interval": cf["checkpoint_interval"]}
+            except Exception as e:                   # never lose the main line because of the extra
+                cfg["config_256"] = {"error": repr(e)}
     if world > 1:
         t = torch.tensor([el], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         scaling = scaling if "slab" in cfg.get("parallelism", "") else "weak"
