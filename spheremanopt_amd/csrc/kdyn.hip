@@ -387,7 +387,26 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         // (read j + k a, write 3 j + k) with one barrier in between, instead of three round trips and three barriers.  The velocity is
         // requested before that barrier and arrives while the others finish reading.  Item = (j, p), p fastest.
         static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
-        fft_inplace_head<L, true, NB, NT, true, false>(buf, LD, tw, tid, ld_spec);
+        // every stored mode feeds two positions of the Hermitian-extended line (kx and G - kx): read it once, coalesced (p fastest: one
+        // 128-byte run per (component, kx)), and write both into the tile; the first butterfly stage then works LDS -> LDS
+        for (int t = tid; t < (L / 3) * NF * 3 * HP; t += NT) {
+            const int p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3), c = fc % 3, f = fc / 3;
+            cplx X1 = mk(0, 0), X2 = mk(0, 0);
+            if (line_ok(p)) {
+                const cplx* src = ((f == 0) ? sp.inA : sp.inB) + tx_off(c, kx, i0 + 2 * p, g);
+                X1 = src[0]; X2 = src[1];
+            }
+            cplx* row = buf + (fc * HP + p) * LD;
+            if (kx == 0) row[0] = mk(X1.re, X2.re);                           // c2r ignores the imaginary part of kx = 0
+            else {
+                row[kx] = mk(X1.re - X2.im, X1.im + X2.re);                   // X1 + i X2
+                row[L - kx] = mk(X1.re + X2.im, X2.re - X1.im);               // conj(X1) + i conj(X2)
+            }
+        }
+        __syncthreads();
+        fft_inplace_head<L, true, NB, NT, true, true>(buf, LD, tw, tid, [&](int b, int pos) -> cplx {
+            return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[b * LD + pos];      // the zero padding is never stored
+        });
         constexpr int S3 = L / 3;
         constexpr int ICNT = (HP * S3 + NT - 1) / NT;
         cplx Win[ICNT][NF][3][3];                   // [item][field group][component][k]: inputs of the last inverse stage
