@@ -112,14 +112,30 @@ static inline void launch_gemm(hipStream_t stream, const GemmDesc* descs, int n,
 //   S_n dense (nout*Nz + xout) x (nin*Nz + xin); fields are [f][2a][Nz] coefficient arrays, extras [2a][3] (row 2n = Re, 2n+1 = Im).
 // One wave per output row; the operators are streamed once: this is the HBM-bound part of a time step.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int APPLY_ROWS = 4;      // 8 measured the same (the input staging is then 12 % instead of 25 % of the operator bytes, both from L2)
 __global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S, const double* __restrict__ in, const double* __restrict__ xin_v,
                                                   double* __restrict__ out, double* __restrict__ xout_v, double* __restrict__ snap, int a, int modes,
                                                   int Nz, int nin, int xin, int nout, int xout, int structure) {
-    const int lane = threadIdx.x & 63;
+    // APPLY_ROWS consecutive rows of ONE mode per workgroup (wave w takes rows w, w + 4, ...): the mode's input vector is staged in the LDS once instead of being fetched through
+    // L1/L2 by every wave (the operator rows are the HBM stream; the input was as many L2 -> L1 requests again).
+    extern __shared__ double2 xs[];                      // cols complex inputs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = nout * Nz + xout, cols = nin * Nz + xin, fcols = nin * Nz;
-    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gr >= (long long)modes * rows) return;
-    const int n = (int)(gr / rows), r = (int)(gr - (long long)n * rows);
+    const int wpm = (rows + APPLY_ROWS - 1) / APPLY_ROWS;      // workgroups per mode
+    const int n = blockIdx.x / wpm, r0 = (blockIdx.x - n * wpm) * APPLY_ROWS + wave;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        double xr, xi;
+        if (c < fcols) {
+            const int fi = c / Nz, j = c - fi * Nz;
+            const size_t e = ((size_t)fi * 2 * a + 2 * n) * Nz + j;
+            xr = in[e]; xi = in[e + Nz];
+        } else {
+            xr = xin_v[(size_t)(2 * n) * 3 + (c - fcols)]; xi = xin_v[(size_t)(2 * n + 1) * 3 + (c - fcols)];
+        }
+        xs[c] = double2{xr, xi};
+    }
+    __syncthreads();
+    for (int r = r0; r < rows && r < r0 + APPLY_ROWS; r += 4) {
     const double2* Srow = S + ((size_t)n * rows + r) * cols;
     // structural zeros of the tau operator: the density block is decoupled from the velocity right-hand sides.  structure 1 (forward
     // operator): density rows (field 2 and extra 2) only see the density columns; structure 2 (its conjugate transpose): the velocity
@@ -130,16 +146,10 @@ __global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S,
     double yr = 0.0, yi = 0.0;
     for (int c = c_lo + lane; c < cols; c += 64) {
         if ((c >= skip_lo && c < skip_hi) || c == skip_x) continue;
-        double xr, xi;
-        if (c < fcols) {
-            const int fi = c / Nz, j = c - fi * Nz;
-            xr = in[((size_t)fi * 2 * a + 2 * n) * Nz + j]; xi = in[((size_t)fi * 2 * a + 2 * n + 1) * Nz + j];
-        } else {
-            xr = xin_v[(size_t)(2 * n) * 3 + (c - fcols)]; xi = xin_v[(size_t)(2 * n + 1) * 3 + (c - fcols)];
-        }
+        const double2 x = xs[c];
         const double2 s = Srow[c];
-        yr += s.x * xr - s.y * xi;
-        yi += s.x * xi + s.y * xr;
+        yr += s.x * x.x - s.y * x.y;
+        yi += s.x * x.y + s.y * x.x;
     }
     for (int off = 32; off > 0; off >>= 1) { yr += __shfl_down(yr, off); yi += __shfl_down(yi, off); }
     if (lane == 0) {
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S,
         } else {
             xout_v[(size_t)(2 * n) * 3 + (r - nout * Nz)] = yr; xout_v[(size_t)(2 * n + 1) * 3 + (r - nout * Nz)] = yi;
         }
+    }
     }
 }
 // The z-derivative variables of the tau system differ from the T-space derivative of u, v, rho only along q = Pre^-1 e_{N-1}
@@ -464,10 +475,10 @@ public:
     // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
     int apply(const double2* S, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int nin, int xin, int nout,
               int xout, int modes, int structure = 0) {
-        const long long rows = (long long)modes * (nout * Nz + xout);
+        const int rows = nout * Nz + xout, cols = nin * Nz + xin;
         ScopedTimer t(timing, k_apply, stream);
-        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, xin_v, out, xout_v, snap, a, modes, Nz, nin, xin,
-                           nout, xout, structure);
+        hipLaunchKernelGGL(pois_apply, dim3((unsigned)(modes * ((rows + APPLY_ROWS - 1) / APPLY_ROWS))), dim3(256), cols * sizeof(double2), stream, S, in, xin_v, out, xout_v,
+                           snap, a, modes, Nz, nin, xin, nout, xout, structure);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
@@ -916,10 +927,10 @@ public:
         return SMO_OK;
     }
     int apply(const double2* S, const double* in, double* out, double* xout, int nin, int nout, int xo) {
-        const long long rows = (long long)a * (nout * Nz + xo);
+        const int rows = nout * Nz + xo, cols = nin * Nz;
         ScopedTimer t(timing, k_apply, stream);
-        hipLaunchKernelGGL(pois_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, S, in, (const double*)nullptr, out, xout, (double*)nullptr, a,
-                           a, Nz, nin, 0, nout, xo, 0);
+        hipLaunchKernelGGL(pois_apply, dim3((unsigned)(a * ((rows + APPLY_ROWS - 1) / APPLY_ROWS))), dim3(256), cols * sizeof(double2), stream, S, in, (const double*)nullptr, out,
+                           xout, (double*)nullptr, a, a, Nz, nin, 0, nout, xo, 0);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
