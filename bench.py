@@ -18,20 +18,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary (profiles/r01_kdyn128_pmc.json:
-    (2*FETCH_SIZE + WRITE_SIZE)*1024, separate counter passes); None if that kernel / size was not profiled."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_kdyn128_pmc.json")))["kernels"]
-    except Exception:
-        return None
-    k = d.get(kernel_name)
-    return k["hbm_bytes_per_launch"] if k else None
+def source_sha():
+    """sha256 over the kernel sources of libsmo (sorted names + contents): the identity a PMC summary must carry to be quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spheremanopt_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_name, npts):
+    """(HBM bytes per launch, provenance) of `kernel_name` at this grid from the rocprofv3 --pmc summary that tools/profile_round.sh
+    leaves under profiles/ ((2*FETCH_SIZE + WRITE_SIZE)*1024, separate counter passes) — but ONLY if that summary was collected from
+    exactly the kernel sources of this tree (source_sha stored beside it); otherwise (None, reason): a counter value from another
+    build is not a measurement of this one."""
+    import glob
+    sha = source_sha()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kdyn%d_pmc.json" % npts)))
+    for f in reversed(cands):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("source_sha") != sha:
+            continue
+        k = d.get("kernels", {}).get(kernel_name)
+        if k:
+            return k["hbm_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "source_sha": sha, "instantiation": k.get("instantiation")}
+    return None, {"reason": "no profiles/r*_kdyn%d_pmc.json collected from these kernel sources (source_sha %s)" % (npts, sha)}
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="number of GPUs = ranks (default: WORLD_SIZE if launched by torchrun, else 1); "
+                    "N > 1 without a launcher: bench.py starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default=None, help="sh23 | shb23 | kdyn | pois (default: kdyn, the largest single-GPU config of BASELINE.json)")
@@ -40,6 +62,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short SH23 / SHB23 lines appended to the default run")
+    ap.add_argument("--no-host-vectors", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg of the kdyn workload")
     ap.add_argument("--replicas", action="store_true", help="N>1: run N independent gradients instead of the slab decomposition")
     return ap.parse_args()
 
@@ -197,22 +220,42 @@ def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
                       "path, %d thread(s)), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers, el)}
 
 
-def _slab_run(torch, N, Rm, dt, n_iters, steps, warm):
+def _slab_elems(N, world):
+    """complex128 elements of ONE field group of one rank's exchange buffer, all peers: 3 * (a/W) * m * G."""
+    return 3 * (N // 2 // world) * (N - 1) * (3 * N // 2)
+
+
+def _slab_run(torch, N, Rm, dt, n_iters, steps, warm, ckpt=1):
     """Build the slab solver for an N^3 problem on this rank's GPU and time `steps` gradients (barrier + sync on both sides)."""
     from spheremanopt_amd import kdyn
-    from spheremanopt_amd.kdyn_slab import SlabKDyn
+    from spheremanopt_amd.kdyn_slab import LibSlabKDyn
     G = 3 * N // 2
-    s = SlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device())
+    # a rank that cannot build its solver (e.g. not enough HBM for its share of the stack) must not leave the others waiting in the
+    # first all-to-all: every rank reports, and all raise together
+    s, err = None, None
+    try:
+        # time loop + transposes inside libsmo: RCCL communicator of its own with the nccl backend (torch.distributed only carries the
+        # 128-byte unique id), the host-staged callback transport with gloo (ranks sharing a GPU in tests)
+        s = LibSlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device(), ckpt=ckpt)
+    except Exception as e:
+        err = e
+    if os.environ.get("SMO_BENCH_INJECT_FAILURE") == str(torch.distributed.get_rank()):     # test hook: this rank fails to construct
+        s, err = None, RuntimeError("injected construction failure")
+    bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
+    torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+    if float(bad.item()) > 0:
+        del s
+        raise RuntimeError("slab solver construction failed on %s" % ("this rank: %r" % (err,) if err is not None else "another rank"))
     Bl = s.local_slab(kdyn.synthetic_field(G, 1)); Ul = s.local_slab(kdyn.synthetic_field(G, 2))
     out = [torch.empty_like(Bl), torch.empty_like(Ul)]
     # warm-up passes time every kernel class (breakdown); the timed region records HIP events only around the dominant one, as on one GPU
     # (events around all ~8 launches of a step pair would cost about as much as a thin slab's kernel)
-    s.ops.ctx.timing_enable(True)
+    s.ctx.timing_enable(True)
     for _ in range(warm):
         s.forward([Bl, Ul]); s.adjoint("Discrete", out)
-    tim_all = s.ops.ctx.timing() if warm else None
+    tim_all = s.ctx.timing() if warm else None
     if tim_all:
-        s.ops.ctx.timing_enable(only=max(range(len(tim_all)), key=lambda i: tim_all[i]["total_ms"]))
+        s.ctx.timing_enable(only=max(range(len(tim_all)), key=lambda i: tim_all[i]["total_ms"] if tim_all[i]["hbm_bytes_per_launch"] > 0 else -1.0))
     torch.cuda.synchronize()
     torch.distributed.barrier()
     t0 = time.perf_counter()
@@ -236,49 +279,57 @@ def bench_kdyn_slab(a, torch, rank, world):
     G = 3 * N // 2
     # integrity check of the decomposition: rank 0 first evaluates J on its own GPU with the single-GPU path (same kernels, no
     # exchange); every rank's slab result must agree with it to 1e-9 relative
-    J_single = torch.zeros(1, dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
+    cdev = "cpu" if torch.distributed.get_backend() == "gloo" else "cuda"
+    J_single = torch.zeros(2, dtype=torch.float64, device=cdev)            # [J, failed]
     if rank == 0:
-        dom1 = kdyn.KDynDomain(N, device=torch.cuda.current_device())
-        J_single[0] = dom1.context(Rm, dt, n_iters, "Final").forward([kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)])
-        dom1.drop_contexts()
+        try:
+            dom1 = kdyn.KDynDomain(N, device=torch.cuda.current_device(), ckpt=0)      # windowed checkpoints if the whole stack does not fit one GPU
+            J_single[0] = dom1.context(Rm, dt, n_iters, "Final").forward([kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)])
+            dom1.drop_contexts()
+        except Exception as e:                   # the other ranks are waiting in the broadcast: tell them instead of leaving
+            sys.stderr.write("rank 0: single-GPU reference J failed (%r)\n" % (e,))
+            J_single[1] = 1.0
     torch.distributed.broadcast(J_single, 0)
+    if float(J_single[1].item()) > 0:
+        raise RuntimeError("single-GPU reference J could not be computed on rank 0")       # raised on EVERY rank
     s, J, el = _slab_run(torch, N, Rm, dt, n_iters, steps, warm)
-    tim = s.ops.ctx.timing()                                   # timed region: the dominant class only (all of them if there was no warm-up)
-    dom_k = max(tim, key=lambda t: t["total_ms"])
+    tim = s.ctx.timing()                                       # timed region: the dominant class only (all of them if there was no warm-up)
+    dom_k = max(tim, key=lambda t: t["total_ms"] if t["hbm_bytes_per_launch"] > 0 else -1.0)
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     brk = s.warmup_timing or tim                               # per-class breakdown from the warm-up gradients
     brk_wall = (el / steps * max(warm, 1)) if s.warmup_timing else el
-    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms, "per_gpu": True,
+            "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
+            "achieved_algorithmic": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
             "kernel_busy_fraction_of_wall": sum(t["total_ms"] for t in brk) / (1e3 * brk_wall),
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1)} for t in brk]}
     roof["frac"] = roof["achieved"] / roof["peak"]
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
-           "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ops.ctx.stack_bytes / 1e9,
-           "slab_J_matches_single_gpu": bool(abs(J - float(J_single.item())) <= 1e-9 * abs(float(J_single.item()))),
-           "J_single_gpu": float(J_single.item()),
-           "parallelism": "slab x%d (kx / z decomposition, RCCL all-to-all between the z and y passes, %d field-group exchanges per "
-                          "step pair, %d pipelined z chunks)" % (world, 3 + s.adj_groups, s.K),
-           "exchange_MB_sent_per_gpu_per_step_pair": (3 + s.adj_groups) * s.elems * 16 / 1e6 * (world - 1) / world,
-           "grid_states_kept_GB_per_gpu": s.ops.ctx.get(1) / 1e9}
+           "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ctx.stack_bytes / 1e9,
+           "slab_J_matches_single_gpu": bool(abs(J - float(J_single[0].item())) <= 1e-9 * abs(float(J_single[0].item()))),
+           "J_single_gpu": float(J_single[0].item()),
+           "parallelism": "slab x%d (kx / z decomposition; time loop and all-to-all transposes between the z and y passes inside libsmo, "
+                          "transport %s; %d field-group exchanges per step pair, %d pipelined z chunks)"
+                          % (world, "RCCL grouped send/recv" if s.transport == "rccl" else "callback (host-staged, test only)",
+                             s.exchanges_per_step_pair, s.K),
+           "transport": s.transport,
+           "exchange_MB_sent_per_gpu_per_step_pair": s.exchanges_per_step_pair * _slab_elems(N, world) * 16 / 1e6 * (world - 1) / world,
+           "grid_states_kept_GB_per_gpu": s.ctx.get(1) / 1e9}
     # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)
     big = int(os.environ.get("SMO_BENCH_SLAB_EXTRA_NPTS", "256"))
     if a.npts is None and a.iters is None and not a.no_secondary and cfg["slab_J_matches_single_gpu"] and (big // 2) % world == 0:
         del s
         torch.cuda.empty_cache()
-        # every rank must be able to hold its 1/W of the snapshot stack plus work buffers; decide collectively, before any allocation
-        need = (n_iters + 1) * 3 * (big // 2 // world) * (big - 1) ** 2 * 16 + 40 * (3 * big // 2) ** 3 * 8 // world + (8 << 30)
-        ok = torch.tensor([1.0 if torch.cuda.mem_get_info()[0] > need else 0.0], dtype=torch.float64, device=J_single.device)
-        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
         try:
-            if ok.item() < 0.5:
-                raise MemoryError("%d^3 needs %.0f GB per GPU at %d slabs" % (big, need / 1e9, world))
-            s2, J2, el2 = _slab_run(torch, big, Rm, dt, n_iters, 1, 0)
+            # ckpt = 0: every rank takes the smallest checkpoint interval whose share of the stack fits its free HBM (2 GPUs: every
+            # snapshot fits; the ranks agree on the interval inside smo_comm_init)
+            s2, J2, el2 = _slab_run(torch, big, Rm, dt, n_iters, 1, 0, ckpt=0)
             cfg["config_256"] = {"workload": "Kinematic dynamo 3D Fourier %d^3 slab-decomposed across %d GPUs, T=%g, dt=%g" % (big, world, dt * n_iters, dt),
                                  "ms_per_gradient": 1e3 * el2, "gradient_evals_per_s": 1.0 / el2, "steps": 1, "warmup": 0, "J": J2,
-                                 "stack_GB_per_gpu": s2.ops.ctx.stack_bytes / 1e9,
-                                 "exchange_MB_sent_per_gpu_per_step_pair": (3 + s2.adj_groups) * s2.elems * 16 / 1e6 * (world - 1) / world}
+                                 "stack_GB_per_gpu": s2.ctx.stack_bytes / 1e9, "checkpoint_interval": int(s2.ctx.get(0)),
+                                 "exchange_MB_sent_per_gpu_per_step_pair": s2.exchanges_per_step_pair * _slab_elems(big, world) * 16 / 1e6 * (world - 1) / world}
             del s2
         except Exception as e:                       # never lose the main line because of the extra
             cfg["config_256"] = {"error": repr(e)}
@@ -286,7 +337,7 @@ def bench_kdyn_slab(a, torch, rank, world):
 
 
 def bench_kdyn(a, torch, rank, world):
-    from spheremanopt_amd import kdyn
+    from spheremanopt_amd import _capi, kdyn
     N = a.npts or 128
     Rm, dt = 1.0, 1e-3
     n_iters = a.iters or 1000
@@ -305,7 +356,8 @@ def bench_kdyn(a, torch, rank, world):
         ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
     tim = ctx.timing()
     tot_ms = sum(t["total_ms"] for t in tim)
-    dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"])
+    # dominant kernel = the byte-moving class with the largest share (the misc class — setup, reductions — has no byte model)
+    dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"] if tim[i]["hbm_bytes_per_launch"] > 0 else -1.0)
     share = tim[dom_i]["total_ms"] / tot_ms
     ctx.timing_enable(only=dom_i)
     torch.cuda.synchronize()
@@ -320,31 +372,68 @@ def bench_kdyn(a, torch, rank, world):
     el = time.perf_counter() - t0
     dom_k = ctx.timing()[dom_i]
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
-    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+
+    def rate(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+    # roofline of the dominant kernel.  `achieved` = compulsory HBM bytes of the kernel AS FUSED (each input read once, each output
+    # written once: DESIGN.md section 4; what a perfect implementation of this kernel must move) / measured launch time, so that
+    # frac <= 1 by construction.  SURVEY 8d's unfused count (every axis pass of every field reads + writes HBM) is carried beside
+    # it as `achieved_algorithmic`: it prices passes the fusion removed and can exceed the peak.
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": rate(dom_k["hbm_bytes_per_launch"], avg_ms),
             "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
+            "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
+            "achieved_algorithmic": rate(dom_k["bytes_per_launch"], avg_ms), "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             "kernel_time_share": share,
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1),
-                             "GBps": (t["bytes_per_launch"] / (t["total_ms"] / max(t["launches"], 1) * 1e-3) / 1e9) if t["launches"] else 0.0}
-                            for t in tim],
-            "whole_gradient_algorithmic_TB": None}
+                             "GBps": rate(t["hbm_bytes_per_launch"], t["total_ms"] / max(t["launches"], 1)) if t["launches"] else 0.0,
+                             "GBps_algorithmic": rate(t["bytes_per_launch"], t["total_ms"] / max(t["launches"], 1)) if t["launches"] else 0.0}
+                            for t in tim]}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    if N == 128 and world == 1:
-        roof["traffic"] = pmc_traffic(dom_k["kernel"])        # measured HBM bytes per launch (rocprofv3 PMC, profiles/)
+    if world == 1:
+        # HBM bytes per launch from the PMC counters: quoted only from a summary collected from exactly these kernel sources
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(dom_k["kernel"], N)
         if roof["traffic"]:
-            roof["measured_traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9
-    roof["note"] = ("achieved = SURVEY 8d algorithmic bytes (every axis pass of every field reads+writes HBM) / measured launch time; the "
-                    "fused kernels move fewer real bytes (traffic), so frac can exceed 1 while the real HBM rate stays below the peak")
-    # whole-job figure with SURVEY 8d's per-step bytes: fwd 6T+9S3+12S0, adj 12T+15S3+24S0
+            roof["measured_traffic_GBps"] = rate(roof["traffic"], avg_ms)
+    roof["note"] = ("achieved = compulsory HBM bytes of the fused kernel / launch time measured with HIP events in this run; "
+                    "achieved_algorithmic = SURVEY 8d's unfused byte count / the same time (may exceed the peak); traffic = PMC "
+                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, or null when no counter run of these sources is committed")
+    # whole-job figures: the compulsory bytes of every launch of one gradient (from the warm-up breakdown) and SURVEY 8d's per-step
+    # bytes (fwd 6T+9S3+12S0, adj 12T+15S3+24S0)
     a_, m_, G_ = N // 2, N - 1, 3 * N // 2
     S0, S1, S2, S3 = 16. * a_ * m_ * m_, 16. * a_ * m_ * G_, 16. * a_ * G_ * G_, 8. * G_ ** 3
     T = S0 + 2 * S1 + 2 * S2 + S3
     per_grad = n_iters * ((6 * T + 9 * S3 + 12 * S0) + (12 * T + 15 * S3 + 24 * S0))
+    per_grad_hbm = sum(t["hbm_bytes_per_launch"] * t["launches"] for t in tim) / max(warm, 1)
+    roof["whole_gradient_TB"] = per_grad_hbm / 1e12
+    roof["whole_gradient_GBps"] = per_grad_hbm / (el / steps) / 1e9
+    roof["whole_gradient_frac"] = roof["whole_gradient_GBps"] / roof["peak"]
     roof["whole_gradient_algorithmic_TB"] = per_grad / 1e12
-    roof["whole_gradient_GBps"] = per_grad / (el / steps) / 1e9
+    roof["whole_gradient_algorithmic_GBps"] = per_grad / (el / steps) / 1e9
+    # SURVEY 8d's metric includes the H2D of X and the D2H of grad J: the same gradient through the host-buffer entry points
+    # (smo_forward / smo_adjoint with pinned host vectors), a few evaluations, reported beside `value`, never as it
+    host = None
+    if world == 1 and not getattr(a, "no_host_vectors", False):
+        hs = max(1, min(steps, 3))
+        hX = [_capi.pinned_copy(B), _capi.pinned_copy(U)]
+        hG = [_capi.pinned_empty(B.size), _capi.pinned_empty(U.size)]
+        ctx.timing_enable(False)
+        ctx.forward(hX); ctx.adjoint(None, out=hG)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(hs):
+            Jh = ctx.forward(hX); ctx.adjoint(None, out=hG)
+        torch.cuda.synchronize()
+        eh = time.perf_counter() - t1
+        host = {"value": hs / eh, "unit": "gradient evals/s", "ms_per_step": 1e3 * eh / hs, "steps": hs,
+                "J_equal": bool(Jh == J), "note": "smo_forward + smo_adjoint on pinned host vectors: H2D of X (2 x %.0f MB) and D2H of grad J "
+                "(2 x %.0f MB) inside the timed region (SURVEY 8d)" % (B.nbytes / 1e6, B.nbytes / 1e6)}
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
            "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "checkpoint_interval": ck, "y_side_stack_GB": ctx.get(1) / 1e9, "J": J,
            "parallelism": "1 GPU" if world == 1 else "replicas only (x%d independent gradients)" % world}
+    if host:
+        cfg["value_host_vectors"] = host
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1)
@@ -352,17 +441,48 @@ def bench_kdyn(a, torch, rank, world):
     return steps, warm, el, 1, roof, cfg, cpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, one process per GPU) and
+    pass their output through.  Runs BEFORE this process imports torch or touches the GPU — a process that has initialised the GPU
+    must never be replaced or forked into ranks."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus is not None and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus is not None and a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line whose "
+                         "n_gpus would not be the number of GPUs asked for" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("SMO_BENCH_BACKEND", "nccl")       # "gloo": ranks sharing one GPU (tests on a one-GPU box)
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s): RCCL needs one GPU per rank (SMO_BENCH_BACKEND=gloo lets ranks "
+                         "share a GPU for tests)" % (world, ndev))
+    torch.cuda.set_device(local % ndev)
     if world > 1:
-        torch.distributed.init_process_group(os.environ.get("SMO_BENCH_BACKEND", "nccl"))   # "gloo": ranks sharing one GPU (tests)
+        import datetime
+        # a rank that dies inside a collective must end the job with an error, not leave the others waiting for ever
+        torch.distributed.init_process_group(backend, timeout=datetime.timedelta(minutes=int(os.environ.get("SMO_BENCH_PG_TIMEOUT_MIN", "15"))))
     wl = a.workload or "kdyn"
     scaling = "weak"
     if wl == "sh23":
@@ -372,6 +492,8 @@ def main():
     elif wl == "pois":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_pois(a, torch, rank, world)
     elif wl == "kdyn" and world > 1 and not a.replicas:
+        cdev = "cpu" if torch.distributed.get_backend() == "gloo" else "cuda"
+        slab_err = None
         try:
             steps, warm, el, per_step_units, roof, cfg, cpu, scaling = bench_kdyn_slab(a, torch, rank, world)
             if not cfg["slab_J_matches_single_gpu"]:
@@ -384,12 +506,12 @@ def main():
                 el2, st2, info, fail = 0.0, 2, {}, 0.0
                 try:
                     torch.cuda.empty_cache()
-                    b = argparse.Namespace(**{**vars(a), "steps": 2, "warmup": 1, "no_cpu_baseline": True})
+                    b = argparse.Namespace(**{**vars(a), "steps": 2, "warmup": 1, "no_cpu_baseline": True, "no_host_vectors": True})
                     torch.distributed.barrier()
                     st2, _, el2, _, _, info, _ = bench_kdyn(b, torch, rank, 1)
                 except Exception as e2:
                     fail, info = 1.0, {"error": repr(e2)}
-                t2 = torch.tensor([el2, fail], device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda", dtype=torch.float64)
+                t2 = torch.tensor([el2, fail], device=cdev, dtype=torch.float64)
                 torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
                 if float(t2[1].item()) > 0:
                     cfg["independent_gradients"] = {"error": info.get("error", "failed on another rank")}
@@ -397,10 +519,17 @@ def main():
                     cfg["independent_gradients"] = {"value": st2 * world / float(t2[0].item()), "unit": "gradient evals/s", "scaling": "weak",
                                                     "ms_per_gradient_per_gpu": 1e3 * float(t2[0].item()) / st2, "steps": st2, "warmup": 1,
                                                     "checkpoint_interval": info["checkpoint_interval"], "y_side_stack_GB": info["y_side_stack_GB"]}
-        except Exception as e:                   # keep the contract (one JSON line) even if the slab path fails on this node
-            sys.stderr.write("rank %d: slab path failed (%r); falling back to independent replicas\n" % (rank, e))
+        except Exception as e:
+            slab_err = e
+        # every rank takes the same branch: the slab result stands only if it succeeded everywhere
+        flag = torch.tensor([0.0 if slab_err is None else 1.0], dtype=torch.float64, device=cdev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if float(flag.item()) > 0:               # keep the contract (one JSON line) even if the slab path fails on this node
+            sys.stderr.write("rank %d: slab path failed (%r); every rank falls back to independent replicas\n" % (rank, slab_err or "on another rank"))
+            torch.cuda.empty_cache()
             steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
-            cfg["slab_path_error"] = repr(e)
+            cfg["slab_path_error"] = repr(slab_err) if slab_err is not None else "failed on another rank"
+            scaling = "weak"
     elif wl == "kdyn":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
     else:
@@ -420,7 +549,7 @@ def main():
         if wl == "kdyn" and a.npts is None and a.iters is None:
             try:
                 torch.cuda.empty_cache()
-                b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": 1, "warmup": 0, "no_cpu_baseline": True})
+                b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": 1, "warmup": 0, "no_cpu_baseline": True, "no_host_vectors": True})
                 st, _, e2, _, _, cf, _ = bench_kdyn(b, torch, rank, world)
                 cfg["config_256"] = {"workload": cf["workload"] + " on 1 GPU", "ms_per_gradient": 1e3 * e2 / st, "gradient_evals_per_s": st / e2,
                                      "steps": st, "warmup": 0, "J": cf["J"], "stack_GB_per_gpu": cf["stack_GB"],
@@ -435,7 +564,9 @@ def main():
     if rank == 0:
         total = steps * per_step_units * world
         out = {"metric": "forward+adjoint gradient evals/sec", "value": total / el, "unit": "gradient evals/s",
-               "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
+               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.get_backend() == "nccl") else (1 if world == 1 else 0)),
+               "backend": (torch.distributed.get_backend() if world > 1 else None),
+               "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
                "roofline": roof, "cpu_baseline": cpu}
         if secondary:

@@ -110,6 +110,27 @@ int smo_forward_dev(smo_ctx* ctx, const double* const* X_dev, double* J_host);
 int smo_adjoint_dev(smo_ctx* ctx, const double* const* X_dev, int adjoint_type, double* const* grad_dev);
 int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double* out_host);
 
+/* ---- device-resident vectors for the caller's own vector algebra ------------------------------------------------
+ * The reference's optimiser does X + alpha*d, coeff*X, -1.*g + beta*t and deepcopy on full-size NumPy vectors
+ * (Sphere_Grad_Descent.py:284, 296-298, 625-690, 755-756, 813) and the callbacks then move them over PCIe on every call.  With
+ * these entry points the vectors stay in HBM (spheremanopt_amd/devvec.py wraps them in a class with +, -, scalar *, deepcopy) and
+ * go to smo_forward_dev / smo_adjoint_dev / smo_inner_dev as they are.
+ *   - buffers come from a per-device pool (smo_vec_free returns them to it; smo_vec_pool_release gives the memory back);
+ *   - smo_vec_axpby: out[i] = fl( fl(a*x[i]) + fl(b*y[i]) ), y == NULL: out[i] = fl(a*x[i]); products and sum are rounded
+ *     separately (no fused multiply-add), i.e. bit for bit what NumPy computes for a*x + b*y; out may alias x or y;
+ *   - all of them are synchronous. */
+int smo_vec_alloc(int device, size_t n, double** out_dev);
+int smo_vec_free(int device, double* dev);
+int smo_vec_pool_release(int device);
+int smo_vec_pool_bytes(int device, size_t* live, size_t* pooled);
+int smo_vec_upload(int device, double* dev, const double* host, size_t n);
+int smo_vec_download(int device, const double* dev, double* host, size_t n);
+int smo_vec_axpby(int device, size_t n, double a, const double* x_dev, double b, const double* y_dev, double* out_dev);
+/* page-locked host memory for the host-buffer entry points (smo_forward / smo_adjoint / smo_inner copy at PCIe rate from / to it;
+ * from pageable memory the runtime stages through its own bounce buffers) */
+int smo_host_alloc(size_t bytes, void** out);
+int smo_host_free(void* p);
+
 /* ---- introspection used by the parity tests and the benchmark ------------------------------------------------ */
 /* Copy snapshot `index` (0..n_iters) of batch member `b` to the host in the reference's GEN_BUFFER element order:
  * SH23 complex128[Nc]; SHB23 float64[N]; KDYN complex128[3][a][m][m]; POIS complex128[3][Nx/2][Nz] (u_fwd, w_fwd, b_fwd of the
@@ -124,13 +145,35 @@ int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out);
  *          non-negative x wavenumbers n = 0..a-1, a = Nx/2 (the other half of the reference's complex spectrum is the Hermitian mirror). */
 int smo_transform(smo_ctx* ctx, int which, const double* in, double* out);
 
-/* ---- slab-decomposed 3-D case: one process per GPU -------------------------------------
+/* ---- slab-decomposed 3-D case: one process per GPU ---------------------------------
  * With smo_config.world > 1 a KDYN context owns the kx-slab [rank*a/world, (rank+1)*a/world) of every coefficient
- * field and the z-slab of every grid field (vectors are then the LOCAL slabs [3][G][G][G/world]); smo_forward /
- * smo_adjoint are replaced by phases between which the host layer performs the pencil transpose (an all-to-all of
- * `elems` complex128 per field group over RCCL: spheremanopt_amd/kdyn_slab.py).  The transpose sits between the z
- * and the y pass, where a field is smallest (16*a*m*G bytes per component).  The two exchange buffers hold
- * [peer][field group][3][a/world][m][G/world] complex128; peer blocks are contiguous, i.e. all_to_all_single-ready.
+ * field and the z-slab of every grid field; vectors are then the LOCAL slabs [3][G][G][G/world].  The pencil transpose sits
+ * between the z and the y pass, where a field is smallest (16*a*m*G bytes per component), as one all-to-all per direction per
+ * step carrying every field of that direction.
+ *
+ * (1) In-library time loop — what the reference gets from Dedalus' in-library MPI transposes (FWD_Solve_KDyn.py:118-134,
+ *     README.md:83 `mpiexec -np 4`): give the context a communicator ONCE, then smo_forward[_dev] / smo_adjoint[_dev] /
+ *     smo_inner[_dev] are called collectively by all ranks exactly like their single-GPU forms (J and <x,y> come back reduced).
+ *       smo_comm_unique_id   rank 0: 128 opaque bytes (an RCCL unique id) to hand to every rank by any means (MPI, a file,
+ *                            torch.distributed, ...);
+ *       smo_comm_init        collective: ncclCommInitRank over smo_config.world ranks; the transposes are then grouped
+ *                            ncclSend/ncclRecv on HIP streams of the solver (chunk-pipelined with the grid-side kernels), the scalar
+ *                            reductions ncclAllReduce;
+ *       smo_comm_set_transport  instead of RCCL: caller-provided all-to-all / all-reduce (tests in which ranks share a GPU or run over
+ *                            gloo); collective as well.
+ *     Both agree, across the ranks, on the checkpoint interval and on whether the grid-side states are kept (every rank takes those
+ *     decisions from its own free HBM) before the first exchange could mismatch.
+ * (2) Phase-level entry (smo_kdyn_op): the same loop cut into the phases between two exchanges, for a host layer that performs
+ *     the transposes itself (spheremanopt_amd/kdyn_slab.py: torch.distributed; kept as the CPU/gloo test harness). */
+typedef int (*smo_alltoall_fn)(void* user, const void* src_dev, void* dst_dev, size_t bytes_per_peer, void* hip_stream);
+typedef int (*smo_allreduce_fn)(void* user, double* host_values, int n);      /* in place: sum over the ranks */
+int smo_comm_unique_id(void* id128);
+int smo_comm_init(smo_ctx* ctx, const void* id128);
+int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn all_to_all, smo_allreduce_fn all_reduce_sum, void* user);
+/* key 0: pipelined z chunks per exchange; 1: field-group exchanges per forward+adjoint step pair; 2: 1 if the transport is RCCL */
+int smo_comm_get(const smo_ctx* ctx, int key, double* value);
+
+/* The exchange buffers hold [chunk][peer][field group][3][a/world][m][G/world/chunks] complex128; peer blocks are contiguous.
  *   z-side buffer: my kx, peer = z block; written by the inverse z pass, read by the forward z pass
  *   y-side buffer: peer = kx block, my z; read by the inverse y pass, written by the forward y pass
  * Phases only enqueue work on the context's stream (see smo_set_stream); SMO_KD_ENERGY / SMO_KD_SYNC synchronise. */
@@ -176,6 +219,10 @@ int         smo_timing_enable(smo_ctx* ctx, int on);
 int         smo_timing_classes(const smo_ctx* ctx);
 int         smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms,
                            double* bytes_per_launch);
+/* Compulsory HBM bytes of one launch of class `k` AS FUSED (every input read once, every output written once) —
+ * the denominator of the roofline fraction.  The algorithmic figure of smo_timing_get also prices the axis passes the fusion removed
+ * and is therefore >= this one. */
+int         smo_timing_hbm_bytes(smo_ctx* ctx, int k, double* bytes_per_launch);
 
 #ifdef __cplusplus
 }

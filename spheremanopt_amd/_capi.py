@@ -21,8 +21,14 @@ ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO
 EXPORTS = [
     "smo_create", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
     "smo_stack_bytes", "smo_get", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
-    "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get",
+    "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get", "smo_timing_hbm_bytes",
+    "smo_vec_alloc", "smo_vec_free", "smo_vec_pool_release", "smo_vec_pool_bytes", "smo_vec_upload", "smo_vec_download", "smo_vec_axpby",
+    "smo_host_alloc", "smo_host_free",
+    "smo_comm_unique_id", "smo_comm_init", "smo_comm_set_transport", "smo_comm_get",
 ]
+
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)      # smo_alltoall_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)                       # smo_allreduce_fn
 
 
 class SmoError(RuntimeError):
@@ -93,6 +99,20 @@ def lib():
     L.smo_timing_enable.argtypes = [vp, C.c_int]
     L.smo_timing_classes.argtypes = [vp]
     L.smo_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp]
+    L.smo_timing_hbm_bytes.argtypes = [vp, C.c_int, dp]
+    L.smo_vec_alloc.argtypes = [C.c_int, C.c_size_t, pp]
+    L.smo_vec_free.argtypes = [C.c_int, vp]
+    L.smo_vec_pool_release.argtypes = [C.c_int]
+    L.smo_vec_pool_bytes.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.smo_vec_upload.argtypes = [C.c_int, vp, vp, C.c_size_t]
+    L.smo_vec_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
+    L.smo_vec_axpby.argtypes = [C.c_int, C.c_size_t, C.c_double, vp, C.c_double, vp, vp]
+    L.smo_host_alloc.argtypes = [C.c_size_t, pp]
+    L.smo_host_free.argtypes = [vp]
+    L.smo_comm_unique_id.argtypes = [vp]
+    L.smo_comm_init.argtypes = [vp, vp]
+    L.smo_comm_set_transport.argtypes = [vp, ALLTOALL_FN, ALLREDUCE_FN, vp]
+    L.smo_comm_get.argtypes = [vp, C.c_int, dp]
     _lib = L
     return L
 
@@ -100,6 +120,29 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise SmoError(rc, lib().smo_last_error().decode())
+
+
+def _preload_torch_rccl():
+    """Same reason as for the HIP runtime: if PyTorch's bundled librccl is going to live in this process, libsmo must use that copy
+    (smo_comm_init picks up an already loaded librccl.so.1 before looking for the system one)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+def comm_unique_id():
+    """128 opaque bytes (an RCCL unique id) made by ONE rank and handed to every rank's Context.comm_init."""
+    _preload_torch_rccl()
+    buf = C.create_string_buffer(128)
+    _check(lib().smo_comm_unique_id(buf))
+    return buf.raw
 
 
 def device_count():
@@ -116,8 +159,42 @@ def _ptr_array(ptrs):
 
 
 def _dev_ptr(t):
-    """Device address of a torch tensor (or a plain int)."""
-    return int(t) if isinstance(t, int) else int(t.data_ptr())
+    """Device address of a DeviceVector (.ptr), a torch tensor (.data_ptr()) or a plain int."""
+    if isinstance(t, int):
+        return t
+    p = getattr(t, "ptr", None)
+    return int(p) if p is not None else int(t.data_ptr())
+
+
+class _PinnedBlock:
+    """Owner of one hipHostMalloc block; the NumPy arrays made from it keep it alive through their .base chain."""
+
+    def __init__(self, nbytes):
+        self.p = C.c_void_p()
+        _check(lib().smo_host_alloc(int(nbytes), C.byref(self.p)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.p.value:
+                lib().smo_host_free(self.p)
+                self.p = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(n):
+    """float64[n] in page-locked host memory (smo_host_alloc): the host-buffer entry points then copy at PCIe rate."""
+    blk = _PinnedBlock(8 * int(n))
+    raw = (C.c_double * int(n)).from_address(blk.p.value)
+    raw._smo_block = blk                       # the ctypes array is the ndarray's base and carries the block
+    return np.frombuffer(raw, dtype=np.float64, count=int(n))
+
+
+def pinned_copy(x):
+    out = pinned_empty(np.asarray(x).size)
+    out[:] = np.asarray(x, dtype=np.float64).reshape(-1)
+    return out
 
 
 class Context:
@@ -166,8 +243,12 @@ class Context:
         _check(lib().smo_forward(self._h, _ptr_array([v.ctypes.data for v in vs]), J.ctypes.data_as(C.POINTER(C.c_double))))
         return float(J[0]) if self.batch == 1 else J
 
-    def adjoint(self, X=None, adjoint_type="Discrete"):
-        grads = [np.empty(self.vec_len * self.batch) for _ in range(self.ncomp)]
+    def adjoint(self, X=None, adjoint_type="Discrete", out=None):
+        """`out`: caller-owned result arrays (e.g. pinned ones), else fresh NumPy arrays like the reference's."""
+        grads = out if out is not None else [np.empty(self.vec_len * self.batch) for _ in range(self.ncomp)]
+        for g in grads:
+            if g.size != self.vec_len * self.batch or g.dtype != np.float64 or not g.flags.c_contiguous:
+                raise ValueError("adjoint(out=): contiguous float64 arrays of %d entries expected" % (self.vec_len * self.batch))
         if X is None:
             xp = _ptr_array([None] * self.ncomp)
         else:
@@ -201,6 +282,42 @@ class Context:
         _check(lib().smo_inner_dev(self._h, _dev_ptr(x), _dev_ptr(y), out.ctypes.data_as(C.POINTER(C.c_double))))
         return float(out[0]) if self.batch == 1 else out
 
+    # -- slab communicator (KDYN, world > 1): the transposes then happen inside smo_forward / smo_adjoint ----------------
+    def comm_init(self, unique_id):
+        """Collective: RCCL communicator over the context's `world` ranks from the 128 bytes of comm_unique_id()."""
+        _preload_torch_rccl()
+        if len(unique_id) != 128:
+            raise ValueError("comm_init: the unique id has 128 bytes")
+        _check(lib().smo_comm_init(self._h, C.create_string_buffer(bytes(unique_id), 128)))
+
+    def comm_set_transport(self, all_to_all, all_reduce_sum):
+        """Collective: caller-provided transport instead of RCCL.  all_to_all(src_dev, dst_dev, bytes_per_peer, hip_stream) and
+        all_reduce_sum(ctypes double pointer, n) are Python callables (exceptions are reported as a failed exchange)."""
+        def a2a(user, src, dst, nbytes, stream):
+            try:
+                all_to_all(src, dst, nbytes, stream)
+                return 0
+            except Exception as e:               # noqa: BLE001 — an exception must not unwind through the C frames
+                self._transport_error = e
+                return 1
+
+        def ared(user, vals, n):
+            try:
+                all_reduce_sum(vals, n)
+                return 0
+            except Exception as e:               # noqa: BLE001
+                self._transport_error = e
+                return 1
+
+        self._transport = (ALLTOALL_FN(a2a), ALLREDUCE_FN(ared))          # keep the thunks alive as long as the context
+        self._transport_error = None
+        _check(lib().smo_comm_set_transport(self._h, self._transport[0], self._transport[1], None))
+
+    def comm_get(self, key):
+        v = C.c_double()
+        _check(lib().smo_comm_get(self._h, int(key), C.byref(v)))
+        return v.value
+
     # -- introspection ------------------------------------------------------------------------------------------------
     def snapshot(self, index, b=0):
         out = np.empty(self.snapshot_len)
@@ -231,5 +348,8 @@ class Context:
             ms = C.c_double()
             by = C.c_double()
             _check(lib().smo_timing_get(self._h, k, C.byref(name), C.byref(n), C.byref(ms), C.byref(by)))
-            res.append({"kernel": name.value.decode(), "launches": n.value, "total_ms": ms.value, "bytes_per_launch": by.value})
+            hb = C.c_double()
+            _check(lib().smo_timing_hbm_bytes(self._h, k, C.byref(hb)))
+            res.append({"kernel": name.value.decode(), "launches": n.value, "total_ms": ms.value, "bytes_per_launch": by.value,
+                        "hbm_bytes_per_launch": hb.value})
         return res

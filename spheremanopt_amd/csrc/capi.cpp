@@ -1,5 +1,6 @@
 // extern "C" surface of libsmo (declarations and reference citations: include/smo.h).
 #include "smo_common.hpp"
+#include "comm.hpp"
 
 using smo::Context;
 
@@ -169,6 +170,28 @@ int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double
     return ctx->impl->kdyn_op(op, i0, i1, p0, p1, out);
 }
 
+int smo_comm_unique_id(void* id128) {
+    if (!id128) { smo::set_error("smo_comm_unique_id: null argument"); return SMO_ERR_ARG; }
+    return smo::SlabComm::unique_id(id128);
+}
+int smo_comm_init(smo_ctx* ctx, const void* id128) {
+    CHECK_CTX(ctx);
+    if (!id128) { smo::set_error("smo_comm_init: null id"); return SMO_ERR_ARG; }
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->comm_init(id128);
+}
+int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user) {
+    CHECK_CTX(ctx);
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->comm_set_transport(a2a, ared, user);
+}
+int smo_comm_get(const smo_ctx* ctx, int key, double* value) {
+    CHECK_CTX(ctx);
+    if (!value || key < 0 || key > 2) { smo::set_error("smo_comm_get: bad argument"); return SMO_ERR_ARG; }
+    *value = ctx->impl->comm_info(key);
+    return SMO_OK;
+}
+
 int smo_set_stream(smo_ctx* ctx, void* hip_stream) {
     CHECK_CTX(ctx);
     SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
@@ -194,6 +217,13 @@ int smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, 
     if (launches) *launches = t.cls[k].launches;
     if (total_ms) *total_ms = t.cls[k].total_ms;
     if (bytes_per_launch) *bytes_per_launch = t.cls[k].bytes_per_launch;
+    return SMO_OK;
+}
+int smo_timing_hbm_bytes(smo_ctx* ctx, int k, double* bytes_per_launch) {
+    CHECK_CTX(ctx);
+    auto& t = ctx->impl->timing;
+    if (k < 0 || k >= (int)t.cls.size() || !bytes_per_launch) { smo::set_error("smo_timing_hbm_bytes: class %d", k); return SMO_ERR_ARG; }
+    *bytes_per_launch = t.cls[k].hbm_bytes;
     return SMO_OK;
 }
 

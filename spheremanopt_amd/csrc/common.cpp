@@ -25,6 +25,16 @@ int DevPool::alloc(void** p, size_t bytes) {
     total += bytes;
     return SMO_OK;
 }
+int DevPool::free_one(void* p) {
+    for (size_t i = 0; i < ptrs.size(); ++i)
+        if (ptrs[i] == p) {
+            SMO_HIP(hipFree(p));
+            ptrs.erase(ptrs.begin() + i);
+            return SMO_OK;
+        }
+    set_error("DevPool::free_one: unknown buffer");
+    return SMO_ERR_ARG;
+}
 void DevPool::release() {
     for (void* p : ptrs) (void)hipFree(p);
     ptrs.clear();

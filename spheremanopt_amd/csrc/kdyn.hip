@@ -25,6 +25,7 @@
 //   nu      : the adjoint's second product is summed over the steps on the grid side (x-transformed) and transformed once
 #include <algorithm>
 
+#include "comm.hpp"
 #include "fft_lds.hpp"
 
 namespace smo {
@@ -628,7 +629,7 @@ public:
         if (idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
         const int w = idx / ck, last = std::min(cfg.n_iters, w * ck + ck - 1);
         scratch_window = w;
-        for (int n = w * ck; n < last; ++n) { SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(-1, 0)); SMO_TRY(fwd_C(n)); }
+        for (int n = w * ck; n < last; ++n) SMO_TRY(step_fwd(n, false));
         return SMO_OK;
     }
     Geom geom(int nfields, int k = 0) const { Geom q = g; q.blk = (size_t)nfields * tzc; q.cblk = (size_t)cfg.world * 2 * tzc; q.zg0 = k * g.Gzl; return q; }
@@ -676,7 +677,7 @@ public:
         snapshot_doubles = 2 * 3 * nmode;
         SMO_TRY(base_init());
         ck = cfg.ckpt;
-        if (ck < 0 || (ck != 1 && W != 1)) { set_error("KDYN: ckpt=%d (windowed checkpointing is single-GPU only)", ck); return SMO_ERR_ARG; }
+        if (ck < 0) { set_error("KDYN: ckpt=%d", ck); return SMO_ERR_ARG; }
         if (ck == 0) {                                       // smallest interval that fits the free HBM (keep 8 GB + work buffers spare)
             size_t free_b = 0, total_b = 0;
             SMO_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -701,24 +702,38 @@ public:
         }
         SMO_TRY(pool.alloc(&d_ty, 2 * fld));
         SMO_TRY(pool.alloc(&d_acc, fld));
-        if (W == 1) { SMO_TRY(pool.alloc(&zs, n_ex)); ys = zs; }      // slabs: the host layer supplies zs / ys (SMO_KD_SET_BUFFERS)
+        // exchange buffers: one and the same on a single GPU; with slabs the z side and the y side are apart (a host layer that does
+        // the transposes itself may still point the context at its own pair: SMO_KD_SET_BUFFERS).  SMO_SLAB_FORCE_EXCHANGE=1 keeps them
+        // apart on ONE rank too, so that a one-GPU box sends every transpose through the real communicator (a self-exchange).
+        { const char* e = getenv("SMO_SLAB_FORCE_EXCHANGE"); force_exchange = (W == 1 && e && atoi(e) == 1); }
+        SMO_TRY(pool.alloc(&zs, n_ex));
+        if (W == 1 && !force_exchange) ys = zs;
+        else SMO_TRY(pool.alloc(&ys, n_ex));
+        SMO_TRY(pool.alloc(&d_red, 8));
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
-        n_part_rows = (cfg.cost == SMO_COST_INTEGRATED && W == 1) ? (size_t)cfg.n_iters + 1 : 1;
+        n_part_rows = (cfg.cost == SMO_COST_INTEGRATED) ? (size_t)cfg.n_iters + 1 : 1;
         SMO_TRY(pool.alloc(&d_part, n_part_rows * NPART));
         h_part.resize(n_part_rows * NPART);
         // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component, per slab)
         const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.a * (double)g.G * g.Gzl, S3 = 8.0 * (double)g.G * g.G * g.Gzl;
+        // second figure = compulsory HBM bytes of the kernel as fused (every input read once, every output written once): the
+        // denominator of the roofline fraction (the algorithmic count above it prices passes the fusion removed)
         k_zi = timing.add_class("kd_z_inverse", 3 * (S0 + S1));
         k_zic = timing.add_class("kd_z_inverse<curl>", 3 * (S0 + S1));
         k_yi = timing.add_class("kd_y_pass<inv>", 3 * (S1 + S2));
         k_yf = timing.add_class("kd_y_pass<fwd>", 3 * (S1 + S2));
-        k_xf = timing.add_class("kd_x_pass<fused_fwd>", 3 * (2 * (S2 + S3) + 3 * S3));           // 3 c2r + 3 r2c passes + pointwise (read B,U write EMF)
-        k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3));           // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2; the running sum's read is not counted)
+        k_xf = timing.add_class("kd_x_pass<fused_fwd>", 3 * (2 * (S2 + S3) + 3 * S3),            // 3 c2r + 3 r2c passes + pointwise (read B,U write EMF)
+                                6 * S2 + 3 * S3);                                             // fused: read B (Ty), U; write the EMF's spectrum
+        k_xa = timing.add_class("kd_x_pass<fused_adj>", 3 * (4 * (S2 + S3) + 5 * S3),            // 6 c2r + 6 r2c + pointwise (read w,U,B_f write F1,F2)
+                                15 * S2 + 3 * S3);                                            // fused: read w, B_f, U, the running sum; write F1, the sum
         const double nxt = fuse_next ? 3 * (S0 + S1) : 0.0;                                     // + the next step's inverse z pass, run on the same tile
-        k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0 + nxt);   // 3 z passes + step (read B,N; write B, snapshot)
-        k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0 + nxt);   // F1 only: F2 is summed on the grid side (nu_B / nu_C)
+        const double nxt_hbm = fuse_next ? 3 * S1 : 0.0;                                        // ... which only adds the write of Tz
+        k_zfu = timing.add_class("kd_z_forward<fwd_update>", 3 * (S1 + S0) + 12 * S0 + nxt,    // 3 z passes + step (read B,N; write B, snapshot)
+                                 3 * S1 + 6 * S0 + nxt_hbm);                                   // fused: read Tz, B_n; write B_{n+1} (the stack IS the state)
+        k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0 + nxt,    // F1 only: F2 is summed on the grid side (nu_B / nu_C)
+                                 3 * S1 + 6 * S0 + (cfg.cost == SMO_COST_INTEGRATED ? 3 * S0 : 0.0) + nxt_hbm);
         k_misc = timing.add_class("kd_misc(setup/terminal/energy/grid io)", 0);
         return SMO_OK;
     }
@@ -937,20 +952,140 @@ public:
         return reduce_partials(E);
     }
 
-    // ---- the three callbacks (single GPU: phases back to back, no exchange) -----------------------------------------
-    int single_only(const char* who) {
-        if (K != 1) { set_error("%s: the z slab is cut into %d chunks (phase-level use only)", who, K); return SMO_ERR_STATE; }
-        if (cfg.world != 1) { set_error("%s: with %d slabs the host layer drives the phases (smo_kdyn_op)", who, cfg.world); return SMO_ERR_STATE; }
+    // ---- slab communicator: the pencil transposes and scalar reductions of the time loop, inside the library ------------------
+    SlabComm comm;
+    bool force_exchange = false;
+    hipStream_t cstream = nullptr;               // exchanges of the chunk pipeline (K > 1) run here, next to the kernels on `stream`
+    hipEvent_t ev_main = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_ph, ev_out;
+    double* d_red = nullptr;
+    bool exchanging() const { return (cfg.world > 1 || force_exchange) && comm.ready(); }
+    ~KDyn() override {
+        (void)hipSetDevice(cfg.device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        for (auto* v : {&ev_in, &ev_ph, &ev_out}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    }
+    // all-to-all of chunk k, nf field groups: z side -> y side (to_y) or back.  Peer blocks are contiguous: [chunk][peer][nf*tzc]
+    int exchange(bool to_y, int nf, int k, hipStream_t s) {
+        if (!exchanging()) return SMO_OK;
+        const size_t off = (size_t)k * (size_t)cfg.world * 2 * tzc;
+        const cplx* src = (to_y ? zs : ys) + off;
+        cplx* dst = (to_y ? ys : zs) + off;
+        if (!to_y) zs_ready_fwd = zs_ready_adj = -1;
+        return comm.alltoall(src, dst, (size_t)nf * tzc * sizeof(cplx), s);
+    }
+    enum { ST_FWD = 0, ST_ADJ = 1 };
+    int grid_phase(int code, int idx, int k) { return code == ST_FWD ? fwd_B(idx, k) : adj_B(idx, k); }
+    // one transpose -> grid work -> transpose back.  K > 1: chunk-pipelined — the K inbound exchanges are issued up front on the
+    // communication stream, every chunk's grid kernels wait (stream-level, never the host) for their chunk only, and the outbound
+    // exchange of chunk k overlaps the kernels of chunk k+1.
+    int stage(int code, int idx, int nf_in, int nf_out) {
+        if (!exchanging() || K == 1) {
+            SMO_TRY(exchange(true, nf_in, 0, stream));
+            SMO_TRY(grid_phase(code, idx, 0));
+            return exchange(false, nf_out, 0, stream);
+        }
+        SMO_HIP(hipEventRecord(ev_main, stream));
+        SMO_HIP(hipStreamWaitEvent(cstream, ev_main, 0));
+        for (int k = 0; k < K; ++k) {
+            SMO_TRY(exchange(true, nf_in, k, cstream));
+            SMO_HIP(hipEventRecord(ev_in[k], cstream));
+        }
+        for (int k = 0; k < K; ++k) {
+            SMO_HIP(hipStreamWaitEvent(stream, ev_in[k], 0));
+            SMO_TRY(grid_phase(code, idx, k));
+            SMO_HIP(hipEventRecord(ev_ph[k], stream));
+            SMO_HIP(hipStreamWaitEvent(cstream, ev_ph[k], 0));
+            SMO_TRY(exchange(false, nf_out, k, cstream));
+            SMO_HIP(hipEventRecord(ev_out[k], cstream));
+        }
+        for (int k = 0; k < K; ++k) SMO_HIP(hipStreamWaitEvent(stream, ev_out[k], 0));
         return SMO_OK;
     }
+    // keep = false: recomputation of a window (checkpointing): the grid-side state of step n is not kept again
+    int step_fwd(int n, bool keep) {
+        SMO_TRY(fwd_A(n));
+        SMO_TRY(stage(ST_FWD, keep ? n : -1, 1, 1));
+        return fwd_C(n);
+    }
+    int grid_to_coeff(const double* X, cplx* out) {
+        for (int k = 0; k < K; ++k) { SMO_TRY(g2c_A(X, k)); SMO_TRY(exchange(false, 1, k, stream)); }
+        return g2c_C(out);
+    }
+    int coeff_to_grid(const cplx* C, bool scaled, double* X) {
+        SMO_TRY(c2g_A(C, scaled));
+        for (int k = 0; k < K; ++k) { SMO_TRY(exchange(true, 1, k, stream)); SMO_TRY(c2g_B(X, k)); }
+        return SMO_OK;
+    }
+    int allreduce(double* v, int n) { return cfg.world > 1 ? comm.allreduce_sum(v, n, stream, d_red) : SMO_OK; }
+
+    // Called once the transport exists (collective): the ranks agree on what each of them decided from its own free HBM — the
+    // checkpoint interval and whether the grid-side states are kept (that fixes how many field groups an adjoint step sends) —
+    // before the first exchange could mismatch, and the chunk pipeline is set up.
+    int comm_attach() {
+        double v[3] = {d_tystack ? 1.0 : 0.0, (double)ck, (double)ck * ck};
+        SMO_TRY(allreduce(v, 3));
+        const double W = cfg.world;
+        if (std::fabs(W * v[2] - v[1] * v[1]) > 0.5) {
+            set_error("KDYN: the ranks chose different checkpoint intervals from their free HBM (mine: %d); pass an explicit smo_config.ckpt", ck);
+            return SMO_ERR_STATE;
+        }
+        if (d_tystack && v[0] < W - 0.5) {               // some rank could not keep the grid-side states: nobody does
+            SMO_HIP(hipStreamSynchronize(stream));
+            SMO_TRY(pool.free_one(d_tystack));
+            stack_bytes -= (size_t)cfg.n_iters * fld * sizeof(cplx);
+            d_tystack = nullptr;
+        }
+        int k = 0;
+        if (const char* e = getenv("SMO_SLAB_CHUNKS")) k = atoi(e);
+        // default: up to 4 chunks of at least 9216 (y,z) points — below that the grid-side kernels are launch-bound and chunking
+        // costs more than it hides (profiles/r01_rccl_one_rank.jsonl)
+        if (k <= 0) k = cfg.world > 1 ? std::max(1, std::min(4, (int)(((size_t)g.G * g.Gzr) / 9216))) : 1;
+        while (k > 1 && (g.Gzr % k || (g.Gzr / k) % 2 || ((size_t)g.G * (g.Gzr / k)) % 4)) --k;
+        if (k != K) SMO_TRY(set_chunks(k));
+        if (!cstream) SMO_HIP(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        if (!ev_main) SMO_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+        for (auto* vec : {&ev_in, &ev_ph, &ev_out})
+            while ((int)vec->size() < K) { hipEvent_t e; SMO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); vec->push_back(e); }
+        have_forward = false;
+        return SMO_OK;
+    }
+    int comm_init(const void* id128) override {
+        if (cfg.world == 1 && !force_exchange) { set_error("smo_comm_init: single-slab context (nothing to exchange)"); return SMO_ERR_STATE; }
+        SMO_TRY(comm.init_rccl(cfg.rank, cfg.world, id128));
+        return comm_attach();
+    }
+    int comm_set_transport(smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user) override {
+        if (cfg.world == 1 && !force_exchange) { set_error("smo_comm_set_transport: single-slab context (nothing to exchange)"); return SMO_ERR_STATE; }
+        SMO_TRY(comm.set_transport(cfg.rank, cfg.world, a2a, ared, user));
+        return comm_attach();
+    }
+    double comm_info(int key) const override {
+        if (key == 0) return (double)K;
+        if (key == 1) return 3.0 + (d_tystack ? 1.0 : 2.0);
+        return comm.is_rccl() ? 1.0 : 0.0;
+    }
+
+    // ---- the three callbacks: phases back to back; with slabs the transposes in between go through the communicator ------------
+    int loop_ok(const char* who) {
+        if ((cfg.world > 1 || force_exchange) && !comm.ready()) {
+            set_error("%s: %d slabs and no communicator — call smo_comm_init (RCCL) or smo_comm_set_transport first, or drive the phases "
+                      "yourself (smo_kdyn_op)", who, cfg.world);
+            return SMO_ERR_STATE;
+        }
+        if (K != 1 && !exchanging()) { set_error("%s: the z slab is cut into %d chunks (phase-level use only)", who, K); return SMO_ERR_STATE; }
+        return need_buffers();
+    }
     int forward_dev(const double* const* X, double* J) override {
-        SMO_TRY(single_only("smo_forward"));
+        SMO_TRY(loop_ok("smo_forward"));
         have_forward = false;
         const int N = cfg.n_iters;
         // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver)
-        SMO_TRY(g2c_A(X[1], 0)); SMO_TRY(g2c_C(d_G));
-        SMO_TRY(c2g_A(d_G, false)); SMO_TRY(c2g_B(nullptr, 0));
-        SMO_TRY(g2c_A(X[0], 0)); SMO_TRY(g2c_C(snap(0)));
+        SMO_TRY(grid_to_coeff(X[1], d_G));
+        SMO_TRY(coeff_to_grid(d_G, false, nullptr));
+        SMO_TRY(grid_to_coeff(X[0], snap(0)));
         double Jacc = 0.0, E = 0.0;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         for (int n = 0; n < N; ++n) {
@@ -958,7 +1093,7 @@ public:
                 ScopedTimer t(timing, k_misc, stream);
                 hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(n), d_part + (size_t)n * NPART, g);
             }
-            SMO_TRY(fwd_A(n)); SMO_TRY(fwd_B(n, 0)); SMO_TRY(fwd_C(n));
+            SMO_TRY(step_fwd(n, true));
         }
         scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
         if (integ) {
@@ -978,33 +1113,43 @@ public:
             Jacc = E;
         }
         SMO_HIP(hipGetLastError());
+        SMO_TRY(allreduce(&Jacc, 1));                        // slabs: every rank holds its share of the spectral sum
         SMO_HIP(hipStreamSynchronize(stream));
+        if (cstream) SMO_HIP(hipStreamSynchronize(cstream));
         *J = -Jacc;
         have_forward = true;
         return SMO_OK;
     }
 
     int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
-        SMO_TRY(single_only("smo_adjoint"));
+        SMO_TRY(loop_ok("smo_adjoint"));
         const int N = cfg.n_iters;
         const bool cont = adjoint_type == SMO_ADJ_CONTINUOUS;
         SMO_TRY(ensure(N));
         SMO_TRY(adj_init(adjoint_type));
         int idx = cont ? N : N - 1;
-        for (int it = 0; it < N; ++it, --idx) { SMO_TRY(ensure(idx)); SMO_TRY(adj_A(idx)); SMO_TRY(adj_B(idx, 0)); SMO_TRY(adj_C(idx)); }
-        SMO_TRY(c2g_A(d_G, !cont)); SMO_TRY(c2g_B(grad[0], 0));
-        SMO_TRY(nu_B(0)); SMO_TRY(nu_C());
-        SMO_TRY(c2g_A(d_nu, false)); SMO_TRY(c2g_B(grad[1], 0));
+        for (int it = 0; it < N; ++it, --idx) {
+            SMO_TRY(ensure(idx));
+            SMO_TRY(adj_A(idx));
+            SMO_TRY(stage(ST_ADJ, idx, adj_groups(idx), 1));
+            SMO_TRY(adj_C(idx));
+        }
+        SMO_TRY(coeff_to_grid(d_G, !cont, grad[0]));
+        for (int k = 0; k < K; ++k) { SMO_TRY(nu_B(k)); SMO_TRY(exchange(false, 1, k, stream)); }
+        SMO_TRY(nu_C());
+        SMO_TRY(coeff_to_grid(d_nu, false, grad[1]));
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
+        if (cstream) SMO_HIP(hipStreamSynchronize(cstream));
         return SMO_OK;
     }
 
-    int inner_dev(const double* x, const double* y, double* out) override {       // this slab's share of <x,y>
+    int inner_dev(const double* x, const double* y, double* out) override {       // <x,y>; slabs without a communicator: this slab's share
         hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
         SMO_HIP(hipGetLastError());
         double s = 0.0;
         SMO_TRY(reduce_partials(&s));
+        if (comm.ready()) SMO_TRY(allreduce(&s, 1));
         *out = s / ((double)g.G * g.G * g.G);
         return SMO_OK;
     }

@@ -65,6 +65,7 @@ struct DevPool {
         SMO_HIP(hipStreamSynchronize(s));
         return SMO_OK;
     }
+    int free_one(void* p);              // give one buffer back before the context goes away
     void release();
 };
 
@@ -76,9 +77,11 @@ std::vector<cplx> twiddles(int L);
 // ---------------------------------------------------------------------------------------------------------
 struct TimingClass {
     std::string name;
-    double bytes_per_launch = 0;     // algorithmic bytes of ONE launch
+    double bytes_per_launch = 0;     // algorithmic bytes of ONE launch (every axis pass of every field reads + writes HBM)
     long long launches = 0;
     double total_ms = 0;
+    double hbm_bytes = 0;            // compulsory HBM bytes of ONE launch of the kernel AS FUSED: each input read once,
+                                     // each output written once; <= bytes_per_launch, and what the roofline fraction is taken against
 };
 
 class Timing {
@@ -86,7 +89,10 @@ public:
     bool on = false;
     int only = -1;                    // -1: time every class; k >= 0: only class k (keeps the event overhead out of the other launches)
     std::vector<TimingClass> cls;
-    int add_class(const char* name, double bytes) { cls.push_back({name, bytes, 0, 0.0}); return (int)cls.size() - 1; }
+    int add_class(const char* name, double bytes, double hbm = -1.0) {
+        cls.push_back({name, bytes, 0, 0.0, hbm < 0 ? bytes : hbm});
+        return (int)cls.size() - 1;
+    }
     void reset();
     void begin(int k, hipStream_t s);
     void end(int k, hipStream_t s);
@@ -142,6 +148,14 @@ public:
         set_error("smo_kdyn_op: not a KDYN context");
         return SMO_ERR_UNSUPPORTED;
     }
+    // slab communicator (KDYN with world > 1): see include/smo.h "in-library time loop"
+    virtual int comm_init(const void* id128) { (void)id128; set_error("smo_comm_init: not a KDYN context"); return SMO_ERR_UNSUPPORTED; }
+    virtual int comm_set_transport(smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user) {
+        (void)a2a; (void)ared; (void)user;
+        set_error("smo_comm_set_transport: not a KDYN context");
+        return SMO_ERR_UNSUPPORTED;
+    }
+    virtual double comm_info(int key) const { (void)key; return 0.0; }
     int set_stream(hipStream_t s);      // run on a caller-owned stream (e.g. torch's current stream) instead of the private one
 
     // host-buffer variants: stage through context-owned device vectors

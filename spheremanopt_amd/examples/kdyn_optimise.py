@@ -2,7 +2,7 @@
 
     Generate_IC -> GEN_BUFFER -> [Adjoint_Gradient_Test] -> Optimise_On_Multi_Sphere(X_0, [M_0, E_0], FWD, ADJ, Inner_Prod_3, ...)
 
-Run:  python -m spheremanopt_amd.examples.kdyn_optimise [--npts 24] [--dt 5e-4] [--max-iters 10] [--test-gradient]
+Run:  python -m spheremanopt_amd.examples.kdyn_optimise [--npts 24] [--dt 5e-4] [--max-iters 10] [--test-gradient] [--device-vectors]
 (defaults = the reference's: Npts = 24, Rm = 1, dt = 5e-4, T = Rm, alpha_k = 100, 10 optimiser iterations).
 """
 import argparse
@@ -21,6 +21,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="N_ITERS (default int(Rm/dt))")
     ap.add_argument("--test-gradient", action="store_true")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--device-vectors", action="store_true",
+                    help="keep X, d, g in HBM (spheremanopt_amd.devvec.DeviceVector): no per-call PCIe traffic, same iterates bit for bit")
     a = ap.parse_args(argv)
 
     Rm, dt, Npts = a.rm, a.dt, a.npts
@@ -30,6 +32,9 @@ def main(argv=None):
     domain, Bx0, Ux = Generate_IC(Npts, (0., 2. * 3.141592653589793), M_0, True, reference_recipe=True, Rm=Rm, dt=dt)
     X_FWD_DICT = GEN_BUFFER(Npts, domain, N_SUB_ITERS)
     X_0, Constraints = [Bx0, Ux], [M_0, E_0]
+    if a.device_vectors:
+        from ..devvec import to_device
+        X_0 = to_device(X_0, domain.device)
     args_IP = (domain, None)
     args_f = [domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, "Final", "Discrete"]
 

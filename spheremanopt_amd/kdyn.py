@@ -15,6 +15,7 @@ HBM-resident snapshot stack.
 import numpy as np
 
 from . import _capi
+from .devvec import DeviceVector
 
 
 class SnapshotStack:
@@ -185,12 +186,14 @@ def FWD_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     """-J(B0, U): J = <B_N,B_N> ("Final") or dt*sum_n <B_n,B_n> ("Integrated"); fills the device snapshot stack."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(Rm, dt, N_ITERS, Cost_function)
-    J = ctx.forward([X0[0], X0[1]])
+    on_device = isinstance(X0[0], DeviceVector)             # vectors already in HBM (devvec.py): no staging copies
+    J = ctx.forward_dev([X0[0], X0[1]]) if on_device else ctx.forward([X0[0], X0[1]])
     for k in ('A_fwd', 'B_fwd', 'C_fwd'):
         X_FWD_DICT[k].ctx = ctx
     if getattr(domain, "write_products", False):           # scalar_data/ and CheckPoints/ like the reference's file handlers
         from . import products
-        products.write_kdyn(domain, ctx, X0, dt, N_ITERS, _coeff_to_grid_host)
+        Xh = [x.numpy() for x in X0] if on_device else X0
+        products.write_kdyn(domain, ctx, Xh, dt, N_ITERS, _coeff_to_grid_host)
     return J
 
 
@@ -198,6 +201,10 @@ def ADJ_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     """[dJ/dB0, dJ/dU] as flat grid vectors; valid right after FWD_Solve_IVP_Lin at the same X0."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(Rm, dt, N_ITERS, Cost_function)
+    if isinstance(X0[0], DeviceVector):                     # device vectors in, device vectors out (fresh ones, like the reference's arrays)
+        grads = [DeviceVector(ctx.vec_len, domain.device) for _ in range(2)]
+        ctx.adjoint_dev([X0[0], X0[1]], grads, Adjoint_type)
+        return grads
     return ctx.adjoint(None, Adjoint_type)
 
 
@@ -209,5 +216,9 @@ def File_Manips(k):
 
 def Inner_Prod_3(x, y, domain, random_arg=None):
     """Sum over the three components of the grid mean of x*y."""
+    if isinstance(x, DeviceVector) and isinstance(y, DeviceVector):
+        return domain.any_context().inner_dev(x, y)
+    if isinstance(x, DeviceVector) or isinstance(y, DeviceVector):
+        raise TypeError("Inner_Prod_3: one operand is a DeviceVector and the other is not")
     return domain.any_context().inner(x, y)
 

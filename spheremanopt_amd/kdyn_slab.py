@@ -329,21 +329,134 @@ class SlabKDyn:
         return self.torch.cat(parts, dim=3).reshape(-1).cpu().numpy()
 
 
+class LibSlabKDyn:
+    """One rank's share of the forward / adjoint solve with the time loop AND the transposes inside libsmo (include/smo.h,
+    "in-library time loop"): the context is given a communicator once and smo_forward_dev / smo_adjoint_dev / smo_inner_dev are then
+    called collectively like their single-GPU forms.  Transport:
+      * "rccl" (default with the nccl backend): rank 0 makes an RCCL unique id, torch.distributed only carries those 128 bytes to
+        the other ranks, and libsmo opens its own communicator (grouped ncclSend/ncclRecv on the solver's HIP streams);
+      * "callback" (default with gloo — ranks sharing a GPU in tests): the library calls back into Python for every exchange, which
+        stages the blocks through the host and torch.distributed's all_to_all_single.
+    Same local-slab interface as SlabKDyn (forward / adjoint / inner / local_slab / gather_full)."""
+
+    def __init__(self, Npts, Rm, dt, N_ITERS, Cost_function="Final", device=None, ckpt=1, transport=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank_world()
+        self.N, self.G = int(Npts), 3 * int(Npts) // 2
+        if (self.N // 2) % self.world or self.G % self.world:
+            raise ValueError("%d slabs do not divide a=%d / G=%d" % (self.world, self.N // 2, self.G))
+        self.Gzl = self.G // self.world
+        self.n_iters, self.cost = int(N_ITERS), Cost_function
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        self.dev = torch.device("cuda", self.device)
+        # a rank that cannot build its context (e.g. not enough HBM for its share of the stack) must not leave the others waiting in
+        # the communicator's rendezvous: every rank reports, all raise together
+        self.ctx, err = None, None
+        try:
+            self.ctx = _capi.Context(_capi.SMO_KDYN, Npts, (0., 2. * np.pi), dt, N_ITERS, Rm, cost=Cost_function, device=self.device,
+                                     rank=self.rank, world=self.world, ckpt=ckpt)
+        except Exception as e:               # noqa: BLE001
+            err = e
+        if self.world > 1:
+            staged = _dist().get_backend() == "gloo"
+            bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device="cpu" if staged else self.dev)
+            _dist().all_reduce(bad, op=_dist().ReduceOp.MAX)
+            if float(bad.item()) > 0 and err is None:
+                self.ctx.close()
+                err = RuntimeError("LibSlabKDyn: another rank could not create its context")
+        if err is not None:
+            raise err
+        self.vec_len = self.ctx.vec_len
+        force = self.world == 1 and os.environ.get("SMO_SLAB_FORCE_EXCHANGE", "0") == "1"
+        self.transport = None
+        if self.world > 1 or force:
+            dist = _dist()
+            if transport is None:
+                transport = "rccl" if dist.get_backend() == "nccl" else "callback"
+            self.transport = transport
+            if transport == "rccl":
+                box = [_capi.comm_unique_id() if self.rank == 0 else None]
+                if self.world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                self.ctx.comm_init(box[0])
+            else:
+                self.ctx.comm_set_transport(self._a2a_host_staged, self._allreduce_host)
+        self.K = int(self.ctx.comm_get(0)) if self.transport else 1
+        self.exchanges_per_step_pair = int(self.ctx.comm_get(1)) if self.transport else 0
+
+    # -- the callback transport: blocks staged through the host, torch.distributed (gloo) in between ----------------------------
+    def _a2a_host_staged(self, src, dst, bytes_per_peer, stream):
+        import ctypes as C
+        torch, L = self.torch, _capi.lib()
+        torch.cuda.synchronize(self.dev)                      # the kernels that produced `src` run on the library's own streams
+        n = bytes_per_peer * self.world // 8
+        h = torch.empty(n, dtype=torch.float64)
+        _capi._check(L.smo_vec_download(self.device, C.c_void_p(src), C.c_void_p(h.data_ptr()), n))
+        r = torch.empty_like(h)
+        if self.world > 1:
+            _dist().all_to_all_single(r, h)
+        else:
+            r.copy_(h)
+        _capi._check(L.smo_vec_upload(self.device, C.c_void_p(dst), C.c_void_p(r.data_ptr()), n))
+
+    def _allreduce_host(self, vals, n):
+        if self.world == 1:
+            return
+        t = self.torch.tensor([vals[i] for i in range(n)], dtype=self.torch.float64)
+        _dist().all_reduce(t)
+        for i in range(n):
+            vals[i] = float(t[i])
+
+    def _sync_inputs(self):
+        self.torch.cuda.current_stream(self.dev).synchronize()     # inputs produced by torch kernels; libsmo runs on its own streams
+
+    def forward(self, X):
+        self._sync_inputs()
+        return self.ctx.forward_dev([X[0], X[1]])
+
+    def adjoint(self, Adjoint_type="Discrete", out=None):
+        if out is None:
+            out = [self.torch.empty(self.vec_len, dtype=self.torch.float64, device=self.dev) for _ in range(2)]
+        self._sync_inputs()
+        self.ctx.adjoint_dev([out[0], out[1]], out, Adjoint_type)
+        return out
+
+    def inner(self, x, y):
+        self._sync_inputs()
+        return self.ctx.inner_dev(x, y)
+
+    local_slab = SlabKDyn.local_slab
+    gather_full = SlabKDyn.gather_full
+
+    @property
+    def host_staged(self):
+        return self.transport != "rccl"
+
+
 # ---- the reference's callback surface on top of the slab solver (replicated full vectors in / out) -----------------------------
 
 class SlabDomain:
     """`domain` slot of args_f / args_IP for the multi-GPU run: caches one SlabKDyn per (Rm, dt, N_ITERS, cost)."""
 
-    def __init__(self, Npts, X=(0., 2. * np.pi), device=None):
+    def __init__(self, Npts, X=(0., 2. * np.pi), device=None, in_library=True, ckpt=1):
+        """in_library=True: the time loop and the transposes run inside libsmo (LibSlabKDyn); False: the Python loop over the
+        phase-level entry (SlabKDyn, the CPU/gloo test harness)."""
         self.Npts, self.interval, self.device = int(Npts), X, device
         self.G = 3 * self.Npts // 2
         self.hypervolume = (X[1] - X[0]) ** 3
+        self.in_library, self.ckpt = in_library, ckpt
         self._solvers = {}
 
     def solver(self, Rm, dt, N_ITERS, Cost_function="Final"):
         key = (float(Rm), float(dt), int(N_ITERS), Cost_function)
         if key not in self._solvers:
-            self._solvers[key] = SlabKDyn(self.Npts, Rm, dt, N_ITERS, Cost_function, device=self.device)
+            if self.in_library:
+                self._solvers[key] = LibSlabKDyn(self.Npts, Rm, dt, N_ITERS, Cost_function, device=self.device, ckpt=self.ckpt)
+            else:
+                self._solvers[key] = SlabKDyn(self.Npts, Rm, dt, N_ITERS, Cost_function, device=self.device)
         return self._solvers[key]
 
     def any_solver(self):

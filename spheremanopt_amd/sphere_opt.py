@@ -374,12 +374,15 @@ def _dump_progress(R):
     try:
         if _MPI is not None and _MPI.COMM_WORLD.rank != 0:
             return
+        rec = dict(vars(R))
+        # vectors that live on the device (anything with a .numpy(), e.g. devvec.DeviceVector) are written as host arrays
+        rec["X_opt"] = [x.numpy() if hasattr(x, "numpy") else x for x in rec["X_opt"]] if len(rec["X_opt"]) else rec["X_opt"]
         if _h5py is not None:
             with _h5py.File('DAL_PROGRESS.h5', 'w') as fh:
-                for key, val in vars(R).items():
+                for key, val in rec.items():
                     fh.create_dataset(key, data=val)
         else:
-            np.savez('DAL_PROGRESS.npz', **{key: np.asarray(val) for key, val in vars(R).items()})
+            np.savez('DAL_PROGRESS.npz', **{key: np.asarray(val) for key, val in rec.items()})
     except Exception:
         pass
 

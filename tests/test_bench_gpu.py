@@ -31,9 +31,17 @@ def test_kdyn_line_contract():
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "achieved_algorithmic", "bytes_per_launch", "traffic_source"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # frac is taken against the compulsory bytes of the fused kernel: a fraction of the peak, never above it; the unfused count rides along
+    assert 0 < r["frac"] <= 1.0 and r["achieved_algorithmic"] >= r["achieved"]
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    # no PMC summary of a 32^3 run is committed: traffic must be null with the reason, not a number from another build / size
+    assert r["traffic"] is None and "reason" in r["traffic_source"]
+    hv = d["config"]["value_host_vectors"]
+    assert hv["value"] > 0 and hv["J_equal"] is True and hv["value"] <= d["value"] * 1.5
+    assert d["rccl_ranks"] == 1 and d["backend"] is None
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -44,6 +52,45 @@ def test_kdyn_line_contract():
 def test_other_workloads_emit_one_line(wl):
     d = _run(["--workload", wl, "--steps", "1", "--warmup", "1", "--iters", "40", "--no-cpu-baseline"])
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and wl[:2].lower() in d["config"]["workload"].lower().replace("swift-hohenberg", "sh").replace("plane-poiseuille", "po")
+
+
+def _launch(args, extra_env=None, launcher_ranks=None, port=29741):
+    env = dict(os.environ, PYTHONPATH=ROOT, SMO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    p = subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    return p, lines
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher (the shape of the driver's command line): bench.py must start two ranks itself —
+    before it touches the GPU — and report n_gpus = 2 (here the two ranks share the box's one GPU and exchange through gloo)."""
+    p, lines = _launch(["--gpus", "2", "--npts", "32", "--iters", "20", "--steps", "2", "--warmup", "1", "--no-secondary"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["config"]["slab_J_matches_single_gpu"] and "slab_path_error" not in d["config"]
+
+
+def test_world_size_other_than_gpus_is_refused():
+    p, lines = _launch(["--gpus", "4", "--npts", "32", "--iters", "20", "--steps", "1", "--warmup", "0", "--no-secondary"], launcher_ranks=2, port=29743)
+    assert p.returncode != 0 and not lines
+    assert "--gpus 4" in p.stderr and "2 rank" in p.stderr
+
+
+def test_failure_on_one_rank_is_agreed_on_by_all():
+    """A rank that cannot build its slab solver (here: injected on rank 1) must not leave the other in a collective: every rank falls
+    back to independent replicas together and the contract's one JSON line still appears."""
+    p, lines = _launch(["--gpus", "2", "--npts", "32", "--iters", "20", "--steps", "1", "--warmup", "1", "--no-secondary"],
+                       extra_env={"SMO_BENCH_INJECT_FAILURE": "1", "SMO_BENCH_PG_TIMEOUT_MIN": "3"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "slab_path_error" in d["config"] and "replicas" in d["config"]["parallelism"]
 
 
 def test_two_rank_line_reports_slab_and_independent_gradients():

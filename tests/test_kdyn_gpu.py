@@ -29,13 +29,16 @@ def _fields(G, dirty=False):
     return B, U
 
 
-@pytest.mark.parametrize("N,n,dt,dirty", [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True),
-                                          (96, 1, 1e-3, False), (128, 2, 1e-3, False)])
-@pytest.mark.parametrize("cost", ["Final", "Integrated"])
-@pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
+_SMALL = [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True)]
+_ALL4 = [(c, a) for c in ("Final", "Integrated") for a in ("Discrete", "Continuous")]
+# every cost / adjoint combination inline up to 64^3; the default one also at 96^3 and 128^3 (the other three at 128^3 — and 256^3 — are
+# compared with the committed oracle fixtures below: 50 / 2 steps of all four, test_config4_fixture / test_config5_fixture)
+_CASES = [(N, n, dt, d, c, a) for (N, n, dt, d) in _SMALL for (c, a) in _ALL4] + \
+         [(96, 1, 1e-3, False, "Final", "Discrete"), (96, 1, 1e-3, True, "Integrated", "Continuous"), (128, 2, 1e-3, False, "Final", "Discrete")]
+
+
+@pytest.mark.parametrize("N,n,dt,dirty,cost,adj", _CASES)
 def test_forward_adjoint_vs_oracle(N, n, dt, dirty, cost, adj):
-    if N >= 64 and (cost, adj) != ("Final", "Discrete"):
-        pytest.skip("large case only for the default configuration")
     dom = kdyn.KDynDomain(N)
     B, U = _fields(dom.G, dirty)
     buf = kdyn.GEN_BUFFER(N, dom, n)
@@ -72,6 +75,72 @@ def test_against_committed_oracle_output(cost):
     dom.drop_contexts()
 
 
+_FIELD_CACHE = {}
+
+
+def _bench_fields(G):
+    """The seeded synthetic fields of SURVEY 8d (B: seed 1, U: seed 2) — what tools/gen_golden_kdyn_big.py fed the oracle."""
+    if G not in _FIELD_CACHE:
+        _FIELD_CACHE.clear()                               # one grid at a time: 2 x 1.36 GB at G = 384
+        _FIELD_CACHE[G] = (kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2))
+    return _FIELD_CACHE[G]
+
+
+def _check_against_fixture(gold, key, J, gB, gU):
+    idx = gold["idx"]
+    Jo = float(gold["J_" + key.split("_")[0]])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (key, J, Jo)
+    for name, g in (("gB", gB), ("gU", gU)):
+        ref = gold["%s_%s" % (key, name)]
+        assert np.linalg.norm(g[idx] - ref) <= RTOL * np.linalg.norm(ref), (key, name)
+        nrm = float(gold["%s_%s_norm" % (key, name)])
+        assert abs(np.linalg.norm(g) - nrm) <= RTOL * nrm, (key, name)
+        # a functional that sees cancellations the norm does not: the seeded projection stored by the generator
+        w = np.random.RandomState(77).standard_normal(4096)
+        proj = float(np.dot(g[:: max(1, g.size // 4096)][:4096], w))
+        assert abs(proj - float(gold["%s_%s_proj" % (key, name)])) <= RTOL * nrm, (key, name)
+
+
+def _fixture_run(fixture, ckpt=1):
+    """HIP path (single GPU, through the C-ABI) against a committed north-star-size oracle fixture, every cost / adjoint combination."""
+    gold = np.load(os.path.join(GOLDEN, fixture))
+    N, n, dt, Rm = int(gold["N"]), int(gold["steps"]), float(gold["dt"]), float(gold["Rm"])
+    dom = kdyn.KDynDomain(N, ckpt=ckpt)
+    B, U = _bench_fields(dom.G)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    for cost in ("Final", "Integrated"):
+        for adj in ("Discrete", "Continuous"):
+            args = [dom, Rm, dt, n, n, buf, cost, adj]
+            J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+            gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+            _check_against_fixture(gold, "%s_%s" % (cost, adj), J, gB, gU)
+        if cost == "Final":                                # the trajectory itself: last / middle snapshot of the stack
+            last = dom.context(Rm, dt, n, cost).snapshot(n).view(np.complex128)
+            assert abs(np.linalg.norm(last) - float(gold["snap_last_norm"])) <= 1e-9 * float(gold["snap_last_norm"])
+            assert np.linalg.norm(last[::9973] - gold["snap_last_sample"]) <= 1e-9 * np.linalg.norm(gold["snap_last_sample"])
+            assert abs(last.sum() - complex(gold["snap_last_sum"])) <= 1e-9 * float(gold["snap_last_norm"]) * np.sqrt(last.size)
+            mid = dom.context(Rm, dt, n, cost).snapshot(n // 2).view(np.complex128)
+            assert abs(np.linalg.norm(mid) - float(gold["snap_mid_norm"])) <= 1e-9 * float(gold["snap_mid_norm"])
+        dom.drop_contexts()
+
+
+def test_config4_fixture():
+    """BASELINE configs[3] (128^3, Rm = 1, dt = 1e-3): 50 of its 1000 steps, all four cost / adjoint combinations, against the oracle
+    run committed as tests/golden/oracle_kdyn_c4_128_n50.npz (tools/gen_golden_kdyn_big.py; the oracle needs ~15 min for it)."""
+    _fixture_run("oracle_kdyn_c4_128_n50.npz")
+
+
+def test_config4_fixture_with_windowed_checkpoints():
+    """The same 50 steps with every 7th snapshot kept (windows that do not divide 50) — the path 256^3 x 1000 steps takes on one GPU."""
+    _fixture_run("oracle_kdyn_c4_128_n50.npz", ckpt=7)
+
+
+def test_config5_fixture():
+    """BASELINE configs[4]'s grid (256^3: the G = 384 kernel instantiations — half tiles, half twiddle table, narrower adjoint x tiles)
+    on ONE GPU against the oracle: tests/golden/oracle_kdyn_c5_256_n2.npz, all four combinations."""
+    _fixture_run("oracle_kdyn_c5_256_n2.npz")
+
+
 def test_taylor_remainder_two_fields():
     """Adjoint_Gradient_Test on the HIP path with both dB and dU perturbed."""
     N, n, dt = 16, 10, 1e-2
@@ -104,11 +173,11 @@ def test_size_independent_properties():
     dom.drop_contexts()
 
 
-@pytest.mark.parametrize("N", [32, 192])
+@pytest.mark.parametrize("N", [32, 192, 256])
 def test_known_answer_single_mode_decay(N):
     """U = 0, B = (0, cos 3x, 0): every CNAB1 step multiplies the mode by (1/dt - 9/2Rm)/(1/dt + 9/2Rm) — an answer that does not
     come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost.  N = 192 (G = 288 = 4*4*2*3*3): a size whose
-    oracle run would take minutes is checked through this closed form."""
+    oracle run would take minutes is checked through this closed form; N = 256 (G = 384): the north-star grid's kernel instantiations."""
     n, dt, Rm = 9, 1e-2, 1.3
     dom = kdyn.KDynDomain(N)
     G = dom.G
@@ -243,3 +312,29 @@ def test_layout_and_fusion_knobs_are_bit_identical(monkeypatch, knob, off, N):
             a, b = res[(stack, None, adj)], res[(stack, off, adj)]
             assert a[0] == b[0] and np.array_equal(a[2], b[2]), (stack, adj)
             assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]), (stack, adj)
+
+
+@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYSTACK", "0")])
+def test_layout_and_fusion_knobs_are_bit_identical_at_G384(monkeypatch, knob, off):
+    """The same pure-performance devices at the north-star grid (N = 256: half tiles, half twiddle table, XCD-paired x tiles): fused next z
+    pass, Ty plane padding, grid-side stack.  Noise inputs (full spectrum, non-solenoidal: every branch of the per-mode update)."""
+    N, n = 256, 3
+    G = 3 * N // 2
+    rs = np.random.RandomState(5)
+    B, U = rs.standard_normal(3 * G ** 3), rs.standard_normal(3 * G ** 3)
+    res = []
+    for val in (None, off):
+        if val is None:
+            monkeypatch.delenv(knob, raising=False)
+        else:
+            monkeypatch.setenv(knob, val)
+        dom = kdyn.KDynDomain(N)
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        args = [dom, 1., 1e-3, n, n, buf, "Integrated", "Discrete"]
+        J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+        g = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        res.append((J, g, dom.context(1., 1e-3, n, "Integrated").snapshot(n)))
+        dom.drop_contexts()
+    a, b = res
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])

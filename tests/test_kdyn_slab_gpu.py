@@ -44,7 +44,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
+def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out, inlib=True, ckpt=1):
     sys.path.insert(0, ROOT)
     # keep == "mixed": only rank 0 would keep the grid-side states (as if the others were short of HBM): the ranks must agree on "none",
     # otherwise the adjoint exchanges would carry different numbers of field groups
@@ -60,34 +60,72 @@ def _worker(rank, world, port, N, n, cost, adj, keep, chunks, out):
         G = 3 * N // 2
         B = kdyn.synthetic_field(G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * G ** 3)
         U = kdyn.synthetic_field(G, 2)
-        dom = kdyn_slab.SlabDomain(N, device=0)
+        dom = kdyn_slab.SlabDomain(N, device=0, in_library=inlib, ckpt=ckpt)
         args = [dom, 1.3, 1e-2, n, n, None, cost, adj]
         J = kdyn_slab.FWD_Solve_IVP_Lin([B, U], *args)              # the reference-style replicated-vector callbacks
         gB, gU = kdyn_slab.ADJ_Solve_IVP_Lin([B, U], *args)
         ip = kdyn_slab.Inner_Prod_3(B, gB, dom)
+        sol = dom.any_solver()
+        assert isinstance(sol, kdyn_slab.LibSlabKDyn if inlib else kdyn_slab.SlabKDyn) and sol.K == (chunks if world > 1 else 1)
+        if inlib:
+            assert sol.transport == "callback" and sol.ctx.comm_get(2) == 0.0
+            assert sol.exchanges_per_step_pair == (4 if keep is True and sol.ctx.get(0) == 1 else 5)
         if rank == 0:
             np.savez(out, J=J, gB=gB, gU=gU, ip=ip, B=B, U=U)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [(16, 2, "Final", "Discrete", True, 1), (32, 4, "Integrated", "Discrete", False, 1),
-                                                          (16, 2, "Final", "Continuous", True, 2), (48, 4, "Final", "Discrete", True, 3),
-                                                          (32, 2, "Final", "Discrete", False, 4), (64, 2, "Integrated", "Continuous", True, 2),
-                                                          (32, 2, "Integrated", "Discrete", True, 1),    # 24 local planes: the halved y-pass tile
-                                                          (16, 2, "Final", "Discrete", "mixed", 1), (16, 2, "Final", "Continuous", "mixed", 2)])
-def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep, chunks):
-    import torch.multiprocessing as mp
+_SLAB_CASES = [(16, 2, "Final", "Discrete", True, 1), (32, 4, "Integrated", "Discrete", False, 1),
+               (16, 2, "Final", "Continuous", True, 2), (48, 4, "Final", "Discrete", True, 3),
+               (32, 2, "Final", "Discrete", False, 4), (64, 2, "Integrated", "Continuous", True, 2),
+               (32, 2, "Integrated", "Discrete", True, 1),    # 24 local planes: the halved y-pass tile
+               (16, 2, "Final", "Discrete", "mixed", 1), (16, 2, "Final", "Continuous", "mixed", 2)]
+
+
+def _check_vs_oracle(out, N, n, cost, adj):
     from oracle.kdyn import KDynOracle
-    n = 3
-    out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, chunks, out), nprocs=world, join=True)
     r = np.load(out)
     o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
     Jo = o.forward([r["B"], r["U"]]); goB, goU = o.adjoint([r["B"], r["U"]], adj)
     assert abs(float(r["J"]) - Jo) <= 1e-6 * abs(Jo)
     assert rel(r["gB"], goB) < 1e-6 and rel(r["gU"], goU) < 1e-6
     assert abs(float(r["ip"]) - o.inner(r["B"], goB)) <= 1e-6 * abs(o.inner(r["B"], goB))
+
+
+@pytest.mark.parametrize("N,world,cost,adj,keep,chunks", _SLAB_CASES)
+def test_in_library_loop_with_ranks_sharing_one_gpu_matches_oracle(tmp_path, N, world, cost, adj, keep, chunks):
+    """The product path of the multi-GPU case: time loop and transposes inside libsmo (smo_comm_set_transport + smo_forward_dev /
+    smo_adjoint_dev / smo_inner_dev called collectively).  The ranks share the box's one GPU, so the transport is the callback one
+    (host-staged gloo) — everything but the ncclSend/ncclRecv group itself is what runs on an 8-GPU node: slab geometry, chunk
+    pipeline on two streams, agreement on the kept grid-side states ("mixed": only rank 0 would keep them), reduced J and <x,y>."""
+    import torch.multiprocessing as mp
+    n = 3
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, chunks, out, True), nprocs=world, join=True)
+    _check_vs_oracle(out, N, n, cost, adj)
+
+
+@pytest.mark.parametrize("N,world,cost,adj,ckpt,n,chunks", [(16, 2, "Final", "Discrete", 3, 7, 1), (32, 2, "Integrated", "Continuous", 2, 5, 2),
+                                                            (16, 4, "Final", "Discrete", 0, 4, 1)])
+def test_windowed_checkpoints_with_slabs(tmp_path, N, world, cost, adj, ckpt, n, chunks):
+    """Windowed checkpointing and the slab decomposition together (the combination a 384^3-class problem needs): the recomputation of
+    a window runs the same exchanging forward steps; ckpt = 0: every rank picks the interval from its free HBM and the ranks must
+    agree on it."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, True, chunks, out, True, ckpt), nprocs=world, join=True)
+    _check_vs_oracle(out, N, n, cost, adj)
+
+
+@pytest.mark.parametrize("N,world,cost,adj,keep,chunks", [_SLAB_CASES[i] for i in (0, 1, 3, 5, 8)])
+def test_ranks_sharing_one_gpu_match_oracle(tmp_path, N, world, cost, adj, keep, chunks):
+    """The phase-level entry (smo_kdyn_op) driven by the Python loop of kdyn_slab.SlabKDyn — the harness the CPU/gloo tests use."""
+    import torch.multiprocessing as mp
+    n = 3
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, chunks, out, False), nprocs=world, join=True)
+    _check_vs_oracle(out, N, n, cost, adj)
 
 
 def _nccl_worker(rank, port, N, n, chunks, out):
@@ -103,8 +141,10 @@ def _nccl_worker(rank, port, N, n, chunks, out):
         dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
         buf = kdyn.GEN_BUFFER(N, dom, n)
         args = [dom, 1., 1e-3, n, n, buf, "Final", "Discrete"]
+        os.environ["SMO_SLAB_FORCE_EXCHANGE"] = "0"          # the monolithic reference: one buffer, no exchange
         J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
         g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        os.environ["SMO_SLAB_FORCE_EXCHANGE"] = "1"
         s = SlabKDyn(N, 1., 1e-3, n, "Final")
         assert s.force_exchange and not s.host_staged and s.buf_y.data_ptr() != s.buf_z.data_ptr() and s.K == chunks
         J1 = s.forward([s.local_slab(B), s.local_slab(U)])
@@ -114,6 +154,50 @@ def _nccl_worker(rank, port, N, n, chunks, out):
                  ip=ip, ip0=kdyn.Inner_Prod_3(B, g0[0], dom))
     finally:
         dist.destroy_process_group()
+
+
+def _lib_rccl_worker(rank, port, N, n, chunks, cost, adj, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMO_SLAB_FORCE_EXCHANGE="1", SMO_SLAB_CHUNKS=str(chunks))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from spheremanopt_amd import kdyn
+        from spheremanopt_amd.kdyn_slab import LibSlabKDyn
+        dom, B, U = kdyn.Generate_IC(N, U_Noise=True)
+        os.environ["SMO_SLAB_FORCE_EXCHANGE"] = "0"
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        args = [dom, 1., 1e-3, n, n, buf, cost, adj]
+        J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+        g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        os.environ["SMO_SLAB_FORCE_EXCHANGE"] = "1"
+        s = LibSlabKDyn(N, 1., 1e-3, n, cost)
+        assert s.transport == "rccl" and s.ctx.comm_get(2) == 1.0 and s.K == chunks
+        J1 = s.forward([s.local_slab(B), s.local_slab(U)])
+        g1 = s.adjoint(adj)
+        g2 = s.adjoint(adj)                                   # a second sweep over the same stack
+        ip = s.inner(s.local_slab(B), g1[0])
+        np.savez(out, J0=J0, J1=J1, eB=np.abs(g1[0].cpu().numpy() - g0[0]).max(), eU=np.abs(g1[1].cpu().numpy() - g0[1]).max(),
+                 e2=np.abs(g2[0].cpu().numpy() - g0[0]).max(), ip=ip, ip0=kdyn.Inner_Prod_3(B, g0[0], dom))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks,cost,adj", [(1, "Final", "Discrete"), (2, "Integrated", "Continuous"), (4, "Final", "Discrete")])
+def test_in_library_rccl_path_on_one_rank(tmp_path, chunks, cost, adj):
+    """smo_comm_init + the in-library loop with REAL RCCL calls (ncclCommInitRank, grouped ncclSend/ncclRecv on the solver's streams,
+    ncclAllReduce of J and <x,y>) on a one-rank communicator with the two exchange buffers kept apart: every transpose is a
+    self-exchange through RCCL, so the result must equal the monolithic single-GPU path bit for bit.  chunks > 1: the two-stream
+    pipeline (exchanges on the communication stream, events in both directions)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_lib_rccl_worker, args=(_free_port(), 32, 4, chunks, cost, adj, out), nprocs=1, join=True)
+    r = np.load(out)
+    assert float(r["J1"]) == float(r["J0"])
+    assert float(r["eB"]) == 0.0 and float(r["eU"]) == 0.0 and float(r["e2"]) == 0.0
+    assert abs(float(r["ip"]) - float(r["ip0"])) < 1e-15
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 4])
@@ -141,10 +225,10 @@ def _big_worker(rank, world, port, N, n, chunks, out):
     try:
         torch.cuda.set_device(0)
         from spheremanopt_amd import kdyn
-        from spheremanopt_amd.kdyn_slab import SlabKDyn
+        from spheremanopt_amd.kdyn_slab import LibSlabKDyn
         G = 3 * N // 2
         B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
-        s = SlabKDyn(N, 1., 1e-3, n, "Final")
+        s = LibSlabKDyn(N, 1., 1e-3, n, "Final")
         assert s.K == chunks
         J = s.forward([s.local_slab(B), s.local_slab(U)])
         g = s.adjoint("Discrete")
@@ -175,3 +259,16 @@ def test_bench_size_slabs_agree_with_the_single_gpu_path(tmp_path, N, world, chu
     r = np.load(out)
     assert abs(float(r["J"]) - J0) <= 1e-12 * abs(J0)
     assert rel(r["gB"], g0[0]) < 1e-12 and rel(r["gU"], g0[1]) < 1e-12
+    if N == 256:
+        # ... and with the ORACLE at the north-star grid (tests/golden/oracle_kdyn_c5_256_n2.npz: same seeds, Rm, dt, 2 steps), so that
+        # the slab path of BASELINE configs[4] is checked against something other than this library
+        from conftest import GOLDEN
+        gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c5_256_n2.npz"))
+        assert int(gold["N"]) == N and int(gold["steps"]) == n and float(gold["dt"]) == 1e-3 and float(gold["Rm"]) == 1.0
+        Jo, idx = float(gold["J_Final"]), gold["idx"]
+        assert abs(float(r["J"]) - Jo) <= 1e-6 * abs(Jo)
+        for name in ("gB", "gU"):
+            ref = gold["Final_Discrete_" + name]
+            assert np.linalg.norm(r[name][idx] - ref) <= 1e-6 * np.linalg.norm(ref)
+            nrm = float(gold["Final_Discrete_%s_norm" % name])
+            assert abs(np.linalg.norm(r[name]) - nrm) <= 1e-6 * nrm
