@@ -96,8 +96,9 @@ int         smo_device_count(int* count);                      /* never initiali
 int smo_ncomp(const smo_ctx* ctx);                              /* number of norm-constrained vectors (1 or 2) */
 int smo_vec_len(const smo_ctx* ctx, size_t* len);               /* doubles per component (per batch member) */
 int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by the snapshot stack(s) */
-/* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: bytes of the y-side stack kept by the forward
- * solve so that the adjoint skips the z/y passes of every snapshot (KDYN, 0 if not in use). */
+/* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: KDYN: bytes of the y-side stack kept by the forward
+ * solve so that the adjoint skips the z/y passes of every snapshot (0 if not in use); SHB23: how many calls fell back from the
+ * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU). */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */

@@ -198,7 +198,9 @@ __device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const do
 //             relaxed agent add on a monotonic counter
 //   consumer: lane 0 polls the counter (relaxed agent load, s_sleep, BOUNDED), agent acquire fence, vmcnt(0) -> barrier -> plain
 //             loads (cdna_hip_programming.md Guideline 16).  Outputs are double-buffered by step parity.
-// A member that times out raises `err` and every member leaves at its next gather: the kernel always terminates.
+// A member that times out raises `err` and every member leaves at its next gather: the kernel always terminates.  The members are
+// NOT launched co-operatively; the host checks beforehand that the GPU can hold them all at once (occupancy query) and, should a
+// member still not arrive (a GPU shared with other work), reruns the call with one workgroup per problem (cluster_retry below).
 // ---------------------------------------------------------------------------------------------------------
 struct Cluster {
     int KC, k, R;                 // members, my index, rows per member
@@ -231,7 +233,8 @@ __device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double
         __hip_atomic_fetch_add(c.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (c.step + 1u) * (unsigned)c.KC;
         int ok = 0;
-        for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+        const unsigned spin_max = c.err[1];          // bounded wait: the host sets the cap (default 2^22 polls) and reruns on a time-out
+        for (unsigned spin = 0; spin < spin_max; ++spin) {
             if (__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             if (__hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             __builtin_amdgcn_s_sleep(2);
@@ -491,6 +494,43 @@ public:
     cplx *d_tw = nullptr, *d_twN = nullptr, *d_tw4 = nullptr;
     int k_fwd = -1, k_adj = -1;
     int KC = 1;                        // cluster size (1 = one workgroup per problem)
+    int spin_log2 = 22;                // a member gives up after 2^spin_log2 polls (SMO_SHB_SPIN_LOG2; tests force the time-out path with 0)
+    bool cluster_off = false;          // a gather timed out once: this context stays with one workgroup per problem
+    long long cluster_fallbacks = 0;
+    int reset_cluster_words() {
+        std::vector<unsigned> w((size_t)cfg.batch + 2, 0u);
+        w[(size_t)cfg.batch + 1] = 1u << spin_log2;
+        SMO_HIP(hipMemcpyAsync(d_clcnt, w.data(), w.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream));
+        SMO_HIP(hipStreamSynchronize(stream));          // `w` is a local
+        return SMO_OK;
+    }
+    // cluster size for this launch: all KC members must be resident at once (they spin on each other), so ask the runtime how many
+    // workgroups of this kernel a CU holds; anything short of KC => one workgroup per problem
+    template <class K> int cluster_size(K kern, size_t lds) {
+        if (KC == 1 || cluster_off) return 1;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, lds) != hipSuccess) return 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg.device) != hipSuccess) return 1;
+        return ((long long)per_cu * cus >= (long long)cfg.batch * KC) ? KC : 1;
+    }
+    // run `launch(kc)`; if a cluster gather timed out (the members were not co-resident after all), run it again with one workgroup
+    // per problem — same arithmetic order inside a row, so the result is what a cluster run would have given up to the reduction order
+    template <class F> int cluster_retry(const char* who, F launch) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int kc = 1;
+            SMO_TRY(launch(attempt == 0 ? -1 : 1, &kc));
+            SMO_HIP(hipGetLastError());
+            unsigned err = 0;
+            SMO_HIP(hipMemcpyAsync(&err, d_clerr, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            SMO_HIP(hipStreamSynchronize(stream));
+            if (err == 0) return SMO_OK;
+            if (kc == 1) { set_error("SHB23 %s: error flag raised without a cluster (internal)", who); return SMO_ERR_HIP; }
+            cluster_off = true; ++cluster_fallbacks;
+        }
+        set_error("SHB23 %s: cluster all-gather timed out and the single-workgroup rerun failed too", who);
+        return SMO_ERR_HIP;
+    }
+    double info(int key) const override { return key == 0 ? 1.0 : (double)cluster_fallbacks; }
     double* d_clbuf = nullptr;
     unsigned *d_clcnt = nullptr, *d_clerr = nullptr;
 
@@ -547,9 +587,10 @@ public:
         const char* env = getenv("SMO_SHB_CLUSTER");
         if (cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) KC = Nc * Nc / 8192;    // N = 1024 would not fit the LDS
         SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * Nc));
-        SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 1));
+        SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 2));          // arrival counters | error flag | spin cap
         d_clerr = d_clcnt + cfg.batch;
-        SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
+        { const char* e = getenv("SMO_SHB_SPIN_LOG2"); spin_log2 = e ? std::max(0, std::min(30, atoi(e))) : 22; }
+        SMO_TRY(reset_cluster_words());
         // algorithmic bytes: stack written/read once + the operator once + the vector
         const double bytes = cfg.batch * ((double)(cfg.n_iters + 1) * snapshot_doubles * 8.0 + N * 8.0) + (double)Nc * Nc * 8.0;
         k_fwd = timing.add_class("shb_forward_kernel", bytes);
@@ -571,20 +612,24 @@ public:
 
     int forward_dev(const double* const* X, double* J) override {
         have_forward = false;
-        SMO_TRY(dispatch([&](auto nh) {
-            constexpr int H = decltype(nh)::value;
-            auto kern = shb_forward_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
-            SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
-            ScopedTimer t(timing, k_fwd, stream);
-            hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                               1.0 / Lz, cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr, Nc, cnts ? 1 : 0);
-            return SMO_OK;
+        SMO_TRY(cluster_retry("forward", [&](int force_kc, int* used) -> int {
+            return dispatch([&](auto nh) -> int {
+                constexpr int H = decltype(nh)::value;
+                auto kern = shb_forward_kernel<H>;
+                const size_t lds_cl = sizeof(ShbShared<H>) + (size_t)(Nc / KC) * Nc * sizeof(double);
+                SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
+                const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
+                const size_t lds = kc > 1 ? lds_cl : sizeof(ShbShared<H>);
+                *used = kc;
+                SMO_TRY(reset_cluster_words());
+                ScopedTimer t(timing, k_fwd, stream);
+                hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                                   1.0 / Lz, cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc, cnts ? 1 : 0);
+                return SMO_OK;
+            });
         }));
-        SMO_HIP(hipGetLastError());
         SMO_HIP(hipMemcpyAsync(J, d_out, cfg.batch * sizeof(double), hipMemcpyDeviceToHost, stream));
-        SMO_TRY(cluster_check("forward"));
+        SMO_HIP(hipStreamSynchronize(stream));
         have_forward = true;
         return SMO_OK;
     }
@@ -595,43 +640,31 @@ public:
                       adjoint_type == SMO_ADJ_CONTINUOUS ? "Continuous" : "Discrete", adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0);
             return SMO_ERR_ARG;
         }
-        if (cnts) {
-            SMO_TRY(dispatch([&](auto nh) {
+        return cluster_retry("adjoint", [&](int force_kc, int* used) -> int {
+            return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
-                auto kern = shb_adjoint_cnts_kernel<H>;
-                const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
-                SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
-                ScopedTimer t(timing, k_adj, stream);
-                hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, d_stack, grad[0], d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                                   cfg.n_iters, KC, d_S, d_clbuf, d_clcnt, d_clerr, Nc);
-                return SMO_OK;
-            }));
-            SMO_HIP(hipGetLastError());
-            return cluster_check("adjoint");
-        }
-        SMO_TRY(dispatch([&](auto nh) {
-            constexpr int H = decltype(nh)::value;
-            auto kern = shb_adjoint_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(N / KC) * N * sizeof(double) : 0);
-            SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            SMO_HIP(hipMemsetAsync(d_clcnt, 0, (cfg.batch + 1) * sizeof(unsigned), stream));
-            ScopedTimer t(timing, k_adj, stream);
-            hipLaunchKernelGGL(kern, dim3(cfg.batch * KC), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                               cfg.n_iters, KC, d_ST, d_clbuf, d_clcnt, d_clerr);
-            return SMO_OK;
-        }));
-        SMO_HIP(hipGetLastError());
-        return cluster_check("adjoint");
-    }
-
-    // wait for the launch and turn a cluster time-out (a member never arrived) into an error instead of garbage
-    int cluster_check(const char* who) {
-        unsigned err = 0;
-        SMO_HIP(hipMemcpyAsync(&err, d_clerr, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        SMO_HIP(hipStreamSynchronize(stream));
-        if (err != 0) { set_error("SHB23 %s: cluster all-gather timed out (the %d workgroups were not co-resident?)", who, KC); return SMO_ERR_HIP; }
-        return SMO_OK;
+                const int No = cnts ? Nc : N;            // operator dimension
+                const size_t lds_cl = sizeof(ShbShared<H>) + (size_t)(No / KC) * No * sizeof(double);
+                auto go = [&](auto kern, auto&& fire) -> int {
+                    SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
+                    const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
+                    *used = kc;
+                    SMO_TRY(reset_cluster_words());
+                    ScopedTimer t(timing, k_adj, stream);
+                    fire(kern, kc, kc > 1 ? lds_cl : sizeof(ShbShared<H>));
+                    return SMO_OK;
+                };
+                if (cnts)
+                    return go(shb_adjoint_cnts_kernel<H>, [&](auto kern, int kc, size_t lds) {
+                        hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, d_stack, grad[0], d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                                           cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc);
+                    });
+                return go(shb_adjoint_kernel<H>, [&](auto kern, int kc, size_t lds) {
+                    hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt,
+                                       cfg.n_iters, kc, d_ST, d_clbuf, d_clcnt, d_clerr);
+                });
+            });
+        });
     }
 
     int inner_dev(const double* x, const double* y, double* out) override {

@@ -153,3 +153,33 @@ def test_continuous_batch_ic_and_errors():
     e = 1e-5
     fd = (shb23.FWD_Solve_IVP_Cnts([X + e * dX], dom2, buf, 100) - shb23.FWD_Solve_IVP_Cnts([X - e * dX], dom2, buf, 100)) / (2 * e)
     assert abs(d - fd) < 1e-2 * abs(fd), (d, fd)
+
+
+@pytest.mark.parametrize("cost,adj", [(0, "Discrete"), (1, "Continuous")])
+def test_cluster_timeout_reruns_with_one_workgroup(monkeypatch, cost, adj):
+    """A cluster member that does not see the others arrive in time (a GPU shared with other work) must not turn a correct call into an
+    error: the call is rerun with one workgroup per problem.  SMO_SHB_SPIN_LOG2=0 caps the wait at ONE poll, which forces the time-out
+    path; the result must be exactly what a context without the cluster (SMO_SHB_CLUSTER=0) returns, and the fallback is counted."""
+    from oracle import shb23 as osh
+    N, n = (512, 60) if cost == 0 else (256, 60)
+    if cost == 0:
+        X = osh.synthetic_ic(osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n), 42, 0.0019)
+    else:
+        X = osh.synthetic_ic_cnts(osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n), 3, 0.0019)
+    monkeypatch.setenv("SMO_SHB_CLUSTER", "0")
+    ref = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=cost)
+    J0, g0 = ref.forward([X]), ref.adjoint(None, adj)[0]
+    assert ref.get(1) == 0
+    monkeypatch.delenv("SMO_SHB_CLUSTER")
+    healthy = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=cost)
+    J1, g1 = healthy.forward([X]), healthy.adjoint(None, adj)[0]
+    assert healthy.get(1) == 0                                    # an idle GPU holds the whole cluster: no fallback
+    assert abs(J1 - J0) <= 1e-12 * abs(J0) and rel(g1, g0) < 1e-10
+    monkeypatch.setenv("SMO_SHB_SPIN_LOG2", "0")
+    ctx = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=cost)
+    J2 = ctx.forward([X])
+    g2 = ctx.adjoint(None, adj)[0]
+    assert ctx.get(1) >= 1, "the one-poll cap did not trigger the time-out path"
+    assert J2 == J0 and np.array_equal(g2, g0)
+    J3 = ctx.forward([X])                                         # the context now stays with one workgroup per problem
+    assert J3 == J0 and ctx.get(1) == 1
