@@ -1,6 +1,6 @@
 // LDS-staged Stockham autosort FFT for gfx950, complex128.
 //
-// A length-L transform is a chain of decimation-in-frequency Stockham stages of radix 4, then 2, then 3
+// A length-L transform is a chain of decimation-in-frequency Stockham stages of radix [8, then] 4, then 2, then 3
 // (L = 4^a 2^b 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..384 incl. 36 = 4*3*3 for Npts = 24).  Stage invariant n*s == L:
 //     y[q + s*(R*p + j)] = w_n^{p*j} * sum_k x[q + s*(p + k*n/R)] * w_R^{j*k},  0 <= p < n/R, 0 <= q < s
 // so (i) the R inputs of consecutive butterflies are consecutive 16-byte elements (conflict-free ds_read_b128 /
@@ -14,7 +14,14 @@
 
 namespace smo {
 
-constexpr __host__ __device__ int radix_of(int n) { return (n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : 3); }
+// Largest butterfly held in registers.  8 (the 3-D passes): 192 = 8*8*3 and 384 = 8*8*2*3 take 3 / 4 stages instead of 4 / 5 — every stage
+// is one round trip through the LDS (a 16-byte ds_write costs 3x a ds_read on gfx950) and one workgroup barrier.
+#ifndef SMO_FFT_MAX_RADIX
+#define SMO_FFT_MAX_RADIX 4
+#endif
+constexpr __host__ __device__ int radix_of(int n) {
+    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : 3));
+}
 constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + stage_count(n / radix_of(n)); }
 constexpr bool fft_length_ok(int n) {
     while (n % 4 == 0) n /= 4;
@@ -47,6 +54,23 @@ template <bool INV> struct Butterfly<4, INV> {
     static __device__ __forceinline__ void run(cplx (&v)[4]) {
         cplx t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = rot90<INV>(v[1] - v[3]);
         v[0] = t0 + t2; v[1] = t1 + t3; v[2] = t0 - t2; v[3] = t1 - t3;
+    }
+};
+
+template <bool INV> struct Butterfly<8, INV> {
+    // radix 2 x radix 4: t = a_k + a_{k+4} feeds the even outputs, u = (a_k - a_{k+4}) w_8^k the odd ones
+    static __device__ __forceinline__ void run(cplx (&v)[8]) {
+        const double H = 0.70710678118654752440084436210485;
+        cplx t[4], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { t[k] = v[k] + v[k + 4]; u[k] = v[k] - v[k + 4]; }
+        u[1] = INV ? mk(H * (u[1].re - u[1].im), H * (u[1].re + u[1].im)) : mk(H * (u[1].re + u[1].im), H * (u[1].im - u[1].re));
+        u[2] = rot90<INV>(u[2]);
+        u[3] = INV ? mk(-H * (u[3].re + u[3].im), H * (u[3].re - u[3].im)) : mk(H * (u[3].im - u[3].re), -H * (u[3].re + u[3].im));
+        Butterfly<4, INV>::run(t);
+        Butterfly<4, INV>::run(u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { v[2 * m] = t[m]; v[2 * m + 1] = u[m]; }
     }
 };
 
@@ -187,56 +211,78 @@ __device__ __forceinline__ void inplace_stage(int tid, TW tw, Load ld, Store st)
 
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
+// Where element (transform b, position pos) of a tile lives in the LDS buffer.
+//   RowMajor{LD}: b * LD + pos — one row per transform (pad LD against bank conflicts);
+//   PosMajor<NB>: pos * NB + b — the NB transforms of a tile interleaved.  With BFAST lane order (consecutive lanes = consecutive
+//   transforms, then consecutive butterflies) every stage READ of a wave is then ONE contiguous 1-KB run — conflict-free for
+//   ds_read_b128 whatever the stage — and all stage writes but the stride-R ones of the first stage are contiguous as well
+//   (tools/lds_conflict_model.py: 26-42 % fewer LDS-array cycles per x-pass tile than the best row padding).
+struct RowMajor {
+    int LD;
+    __device__ __forceinline__ int operator()(int b, int pos) const { return b * LD + pos; }
+};
+template <int NB> struct PosMajor {
+    __device__ __forceinline__ int operator()(int b, int pos) const { return pos * NB + b; }
+};
+
 template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS> struct InplaceTail {
-    template <class TW, class StoreN, class PreLast>
-    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, TW tw, StoreN stN, PreLast pre) {
+    template <class IX, class TW, class StoreN, class PreLast>
+    static __device__ __forceinline__ void run_ix(cplx* buf, IX ix, int tid, TW tw, StoreN stN, PreLast pre) {
         constexpr int R = radix_of(N);
-        auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
+        auto ldL = [&](int b, int pos) { return buf[ix(b, pos)]; };
         if constexpr (N / R == 1) {
             pre();
             inplace_stage<L, N, S, INV, NB, NT, BFAST, LAST_LDS>(tid, tw, ldL, stN);
         } else {
-            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
             __syncthreads();
-            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN, pre);
+            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run_ix(buf, ix, tid, tw, stN, pre);
         }
+    }
+    template <class TW, class StoreN, class PreLast>
+    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, TW tw, StoreN stN, PreLast pre) {
+        run_ix(buf, RowMajor{LD}, tid, tw, stN, pre);
     }
 };
 
 // `pre` runs right before the last stage: the place to issue global loads whose results are needed after the transform (they are
 // then in flight during the last stage instead of being waited for after it, and live in registers for one stage only).
-template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class TW, class Load0, class StoreN, class PreLast = NoPrefetch>
-__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, TW tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class IX, class TW, class Load0, class StoreN, class PreLast = NoPrefetch>
+__device__ __forceinline__ void fft_inplace_ix(cplx* buf, IX ix, TW tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
     constexpr int R0 = radix_of(L);
     static_assert(L / R0 > 1, "transform needs at least two stages");
-    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
     __syncthreads();
-    InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run(buf, LD, tid, tw, stN, pre);
+    InplaceTail<L, L / R0, R0, INV, NB, NT, BFAST, LAST_LDS>::run_ix(buf, ix, tid, tw, stN, pre);
+}
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, bool LAST_LDS, class TW, class Load0, class StoreN, class PreLast = NoPrefetch>
+__device__ __forceinline__ void fft_inplace(cplx* buf, int LD, TW tw, int tid, Load0 ld0, StoreN stN, PreLast pre = PreLast()) {
+    fft_inplace_ix<L, INV, NB, NT, BFAST, FIRST_LDS, LAST_LDS>(buf, RowMajor{LD}, tw, tid, ld0, stN, pre);
 }
 
 // All stages but the last one (LDS -> LDS, a barrier after each): for callers that fuse their own work into the last stage, whose
 // butterfly j reads and writes the same positions j + (L/R) k — thread-local, so it needs no barrier before what follows on those values.
 template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST> struct InplaceHead {
-    template <class TW>
-    static __device__ __forceinline__ void run(cplx* buf, int LD, int tid, TW tw) {
+    template <class IX, class TW>
+    static __device__ __forceinline__ void run(cplx* buf, IX ix, int tid, TW tw) {
         constexpr int R = radix_of(N);
         if constexpr (N / R > 1) {
-            auto ldL = [&](int b, int pos) { return buf[b * LD + pos]; };
-            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+            auto ldL = [&](int b, int pos) { return buf[ix(b, pos)]; };
+            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
             __syncthreads();
-            InplaceHead<L, N / R, S * R, INV, NB, NT, BFAST>::run(buf, LD, tid, tw);
+            InplaceHead<L, N / R, S * R, INV, NB, NT, BFAST>::run(buf, ix, tid, tw);
         }
     }
 };
 template <int L> constexpr int last_radix() { int n = L; while (n / radix_of(n) > 1) n /= radix_of(n); return n; }
 
-template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, class TW, class Load0>
-__device__ __forceinline__ void fft_inplace_head(cplx* buf, int LD, TW tw, int tid, Load0 ld0) {
+template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, class IX, class TW, class Load0>
+__device__ __forceinline__ void fft_inplace_head(cplx* buf, IX ix, TW tw, int tid, Load0 ld0) {
     constexpr int R0 = radix_of(L);
     static_assert(L / R0 > 1, "transform needs at least two stages");
-    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; });
+    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
     __syncthreads();
-    InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST>::run(buf, LD, tid, tw);
+    InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST>::run(buf, ix, tid, tw);
 }
 
 }  // namespace smo

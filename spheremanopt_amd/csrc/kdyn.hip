@@ -278,8 +278,10 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
 // ---------------------------------------------------------------------------------------------------------
 template <int L, bool INV, int ZT, int NT>
 __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw_g, Geom g) {
-    constexpr int LD = L + 1;
-    __shared__ cplx buf[ZT * LD];
+    // position-major tile (PosMajor, fft_lds.hpp): the ZT columns of a tile interleaved, every stage access of a wave is one contiguous
+    // run (model: G = 192 reads 2x -> 1x, G = 384 3x -> 1x conflict cycles against rows of L + 1)
+    constexpr PosMajor<ZT> ix{};
+    __shared__ cplx buf[ZT * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
         auto stN = [&](int b, int pos, cplx v) {
             if (z0 + b < g.Gzl) out[trow + (size_t)pos * g.Gzl + b] = v;
         };
-        fft_inplace<L, true, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
+        fft_inplace_ix<L, true, ZT, NT, true, false, false>(buf, ix, tw, tid, ld0, stN);
     } else {
         auto ld0 = [&](int b, int pos) -> cplx {
             if (z0 + b >= g.Gzl) return mk(0, 0);
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
             const int idx = wrap_pos(pos, g);
             if (idx >= 0 && z0 + b < g.Gzl) out[zrow + (size_t)idx * g.Gzl + b] = v;
         };
-        fft_inplace<L, false, ZT, NT, true, false, false>(buf, LD, tw, tid, ld0, stN);
+        fft_inplace_ix<L, false, ZT, NT, true, false, false>(buf, ix, tw, tid, ld0, stN);
     }
 }
 
@@ -322,6 +324,17 @@ enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
 // element (b, pos) starts at bank group (pad * b + pos) mod 16, and a 64-lane 16-byte access is conflict-free when each of the 16
 // groups gets 4 lanes, i.e. when the NB ranges [pad * b, pad * b + 64/NB) tile the line: pad ~ 64 / NB.
 constexpr int x_ld_pad(int NB) { return NB == 12 ? 5 : (NB == 6 ? 10 : 1); }
+// Layout of the fused x passes' tile: position-major (the NB transforms of a tile interleaved, see PosMajor in fft_lds.hpp) — every
+// stage read of a wave is one contiguous run, no row padding needed.  SMO_X_POSMAJOR=0 builds the row-per-transform layout (ablation).
+#ifndef SMO_X_POSMAJOR
+#define SMO_X_POSMAJOR 1
+#endif
+template <int L, int NB, bool FUSED> struct XLayout {
+    static constexpr bool PM = FUSED && SMO_X_POSMAJOR;
+    static constexpr int LD = L + x_ld_pad(NB);
+    static constexpr int ELEMS = PM ? NB * L : NB * LD;
+    __device__ __forceinline__ int operator()(int b, int pos) const { return PM ? pos * NB + b : b * LD + pos; }
+};
 
 // spectra of the x pass: field groups A / B are read from in* and written to out* (same layout; in == out means in place)
 struct XSpec {
@@ -337,7 +350,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
-    constexpr int LD = L + x_ld_pad(NB);
+    constexpr XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ)> ix{};
     const size_t plane = (size_t)g.G * g.Gzl;       // local (y,z) points
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
@@ -363,10 +376,10 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         const double* q = gridU + grid_off(c, pos, i0 + 2 * p, g);
         return mk(q[0], q[1]);
     };
-    auto st_buf = [&](int b, int pos, cplx v) { buf[b * LD + pos] = v; };
+    auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
 
     if (MODE == X_TO_GRID) {
-        fft_inplace<L, true, NB, NT, true, false, false>(buf, LD, tw, tid, ld_spec, [&](int b, int pos, cplx v) {
+        fft_inplace_ix<L, true, NB, NT, true, false, false>(buf, ix, tw, tid, ld_spec, [&](int b, int pos, cplx v) {
             const int p = b % HP, c = b / HP;
             if (line_ok(p)) {
                 double* q = gridOut + (g.utile ? u_off(c, pos, i0 + 2 * p, g) : grid_off(c, pos, i0 + 2 * p, g));
@@ -379,7 +392,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     constexpr int SCNT = ((L / 3) * NF * 3 * HP + NT - 1) / NT;        // items per thread of the final split / store loop
     cplx old_sum[ACC ? SCNT : 1][2];
     if (MODE == X_FROM_GRID) {
-        fft_inplace<L, false, NB, NT, true, false, true>(buf, LD, tw, tid, ld_grid, st_buf);
+        fft_inplace_ix<L, false, NB, NT, true, false, true>(buf, ix, tw, tid, ld_grid, st_buf);
     } else {
         // The middle of the pass runs in registers.  G = 3N/2, so the inverse transform (radix order 4..4[2]3) ENDS with a radix-3
         // butterfly over x = j, j + a, j + 2a (a = L/3), and the forward transform, taken in the order 3 4..4[2], BEGINS with a radix-3
@@ -397,16 +410,16 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                 const cplx* src = ((f == 0) ? sp.inA : sp.inB) + tx_off(c, kx, i0 + 2 * p, g);
                 X1 = src[0]; X2 = src[1];
             }
-            cplx* row = buf + (fc * HP + p) * LD;
-            if (kx == 0) row[0] = mk(X1.re, X2.re);                           // c2r ignores the imaginary part of kx = 0
+            const int b = fc * HP + p;
+            if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);                    // c2r ignores the imaginary part of kx = 0
             else {
-                row[kx] = mk(X1.re - X2.im, X1.im + X2.re);                   // X1 + i X2
-                row[L - kx] = mk(X1.re + X2.im, X2.re - X1.im);               // conj(X1) + i conj(X2)
+                buf[ix(b, kx)] = mk(X1.re - X2.im, X1.im + X2.re);            // X1 + i X2
+                buf[ix(b, L - kx)] = mk(X1.re + X2.im, X2.re - X1.im);        // conj(X1) + i conj(X2)
             }
         }
         __syncthreads();
-        fft_inplace_head<L, true, NB, NT, true, true>(buf, LD, tw, tid, [&](int b, int pos) -> cplx {
-            return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[b * LD + pos];      // the zero padding is never stored
+        fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
+            return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];        // the zero padding is never stored
         });
         constexpr int S3 = L / 3;
         constexpr int ICNT = (HP * S3 + NT - 1) / NT;
@@ -419,7 +432,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     for (int c = 0; c < 3; ++c)
-                        for (int k = 0; k < 3; ++k) Win[i][f][c][k] = buf[((f * 3 + c) * HP + p) * LD + j + S3 * k];
+                        for (int k = 0; k < 3; ++k) Win[i][f][c][k] = buf[ix((f * 3 + c) * HP + p, j + S3 * k)];
                 if (i == 0)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
@@ -458,10 +471,10 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                     for (int k = 0; k < 3; ++k)
                         v[k] = mk(X[k][c1].re * Y[k][c2].re - X[k][c2].re * Y[k][c1].re, X[k][c1].im * Y[k][c2].im - X[k][c2].im * Y[k][c1].im);
                     Butterfly<3, false>::run(v);
-                    cplx* row = buf + ((f * 3 + c) * HP + p) * LD + 3 * j;
-                    row[0] = v[0];
-                    row[1] = twmul<false>(v[1], tw[j]);
-                    row[2] = twmul<false>(v[2], tw[2 * j]);
+                    const int b = (f * 3 + c) * HP + p;
+                    buf[ix(b, 3 * j)] = v[0];
+                    buf[ix(b, 3 * j + 1)] = twmul<false>(v[1], tw[j]);
+                    buf[ix(b, 3 * j + 2)] = twmul<false>(v[2], tw[2 * j]);
                 }
             };
             last_stage(0, W);
@@ -476,7 +489,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         __syncthreads();
         // remaining forward stages (sub-length a, stride 3); group B of the adjoint pass is a running sum: its old values are requested
         // before the last stage
-        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run(buf, LD, tid, tw, st_buf, [&]() {
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
             if (ACC) {
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
@@ -498,8 +511,8 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         const int p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3);
         if (!line_ok(p)) continue;
         const int c = fc % 3, f = fc / 3;
-        const cplx Zk = buf[(fc * HP + p) * LD + kx];
-        const cplx Zm = conj(buf[(fc * HP + p) * LD + ((kx == 0) ? 0 : L - kx)]);
+        const cplx Zk = buf[ix(fc * HP + p, kx)];
+        const cplx Zm = conj(buf[ix(fc * HP + p, (kx == 0) ? 0 : L - kx)]);
         cplx* dst = ((f == 0) ? sp.outA : sp.outB) + tx_off(c, kx, i0 + 2 * p, g);
         cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
         if (ACC && f == 1) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
@@ -515,7 +528,7 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
-    __shared__ cplx buf[NB * (L + x_ld_pad(NB))];
+    __shared__ cplx buf[XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ)>::ELEMS];
     // G > 192: half twiddle table — with the full one (6 KB at G = 384) the tile fits only three times into a CU's LDS instead of four
     constexpr bool HALF = (L > 192);
     constexpr int NTW = HALF ? L / 2 : L;

@@ -616,7 +616,7 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 auto kern = shb_forward_kernel<H>;
-                const size_t lds_cl = sizeof(ShbShared<H>) + (size_t)(Nc / KC) * Nc * sizeof(double);
+                const size_t lds_cl = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
                 SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                 const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
                 const size_t lds = kc > 1 ? lds_cl : sizeof(ShbShared<H>);
@@ -644,7 +644,7 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 const int No = cnts ? Nc : N;            // operator dimension
-                const size_t lds_cl = sizeof(ShbShared<H>) + (size_t)(No / KC) * No * sizeof(double);
+                const size_t lds_cl = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(No / KC) * No * sizeof(double) : 0);
                 auto go = [&](auto kern, auto&& fire) -> int {
                     SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                     const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
