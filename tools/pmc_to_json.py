@@ -31,6 +31,17 @@ def classify(name):
     return base
 
 
+def source_sha():
+    """Identity of the kernel sources the counters were collected from (same function as bench.py's): bench.py quotes `traffic` only
+    from a summary whose source_sha equals the one of the tree it runs in."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "spheremanopt_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -56,7 +67,7 @@ def main():
             res[k]["wait_any_fraction"] = v["SQ_WAIT_ANY"] / max(v["SQ_WAVE_CYCLES"], 1)
     json.dump({"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), averages per dispatch; hbm_bytes = "
                        "(2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-B "
-                       "requests as 64 B; narrower accesses are uncalibrated)", "grid": sys.argv[3] if len(sys.argv) > 3 else "",
+                       "requests as 64 B; narrower accesses are uncalibrated)", "grid": sys.argv[3] if len(sys.argv) > 3 else "", "source_sha": source_sha(),
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items()):
         print("%-34s %8.1f MB%s" % (k, v["hbm_bytes_per_launch"] / 1e6,

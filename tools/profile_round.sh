@@ -1,19 +1,30 @@
 #!/bin/bash
-# Round profile: rocprofv3 kernel statistics of the benchmark command and HBM traffic counters (separate --pmc passes) of a short KDyn run.
-# Run on the GPU box from the repository root; writes under gpurun_out/prof_round/.
+# Round profile (run on the GPU box from the repository root; writes under gpurun_out/prof_round/):
+#   1. rocprofv3 --kernel-trace --stats of the benchmark command itself (per-kernel average durations to set against bench.py's HIP events)
+#   2. HBM traffic counters, separate --pmc passes (FETCH_SIZE | WRITE_SIZE), of a short KDyn run at 128^3 and 256^3
+#      -> pmc_<N>.json stamped with the sha of the kernel sources (bench.py quotes `traffic` only from a summary of the same sources)
+#   3. kernel statistics of the Poiseuille path
+# usage: tools/profile_round.sh [bench steps]
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_round
+STEPS=${1:-5}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o kdyn128 -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o kdyn128 -- python3 $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-secondary --no-host-vectors > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $R/tools/prof_kdyn.py 128 4 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $R/tools/prof_kdyn.py 128 4 > $OUT/pmc_write.log 2>&1
-echo "pmc done"
+for N in 128 256; do
+  IT=4; [ $N = 256 ] && IT=2
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${N}/fetch -o f -- python3 $R/tools/prof_kdyn.py $N $IT > $OUT/pmc_${N}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${N}/write -o w -- python3 $R/tools/prof_kdyn.py $N $IT > $OUT/pmc_${N}_write.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${N} -o s -- python3 $R/tools/prof_kdyn.py $N $IT > $OUT/stats_${N}.log 2>&1
+  echo "pmc $N done"
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pois_stats -o pois -- python3 $R/tools/prof_pois.py 384 192 200 1 > $OUT/pois_under_rocprof.json 2> $OUT/pois_under_rocprof.err
 echo "pois done"
 cd $R
-python3 tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.txt
-python3 tools/pmc_to_json.py $OUT $OUT/pmc.json 128 || true
-find $OUT -name "*kernel_stats.csv" | head
+for N in 128 256; do
+  python3 tools/summarize_pmc.py $OUT/pmc_${N} > $OUT/pmc_${N}_summary.txt
+  python3 tools/pmc_to_json.py $OUT/pmc_${N} $OUT/pmc_${N}.json $N || true
+done
+find $OUT -name "*kernel_stats.csv"
