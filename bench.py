@@ -220,6 +220,16 @@ def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
                       "path, %d thread(s)), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers, el)}
 
 
+class _PyLoop:
+    """kdyn_slab.SlabKDyn (Python time loop, torch.distributed collectives) behind the attribute names bench.py reads from LibSlabKDyn."""
+
+    def __init__(self, p):
+        self.p, self.ctx, self.K = p, p.ops.ctx, p.K
+        self.transport = "torch.distributed all_to_all_single (Python loop)"
+        self.exchanges_per_step_pair = 3 + p.adj_groups
+        self.forward, self.adjoint, self.local_slab = p.forward, p.adjoint, p.local_slab
+
+
 def _slab_elems(N, world):
     """complex128 elements of ONE field group of one rank's exchange buffer, all peers: 3 * (a/W) * m * G."""
     return 3 * (N // 2 // world) * (N - 1) * (3 * N // 2)
@@ -231,21 +241,39 @@ def _slab_run(torch, N, Rm, dt, n_iters, steps, warm, ckpt=1):
     from spheremanopt_amd.kdyn_slab import LibSlabKDyn
     G = 3 * N // 2
     # a rank that cannot build its solver (e.g. not enough HBM for its share of the stack) must not leave the others waiting in the
-    # first all-to-all: every rank reports, and all raise together
-    s, err = None, None
-    try:
-        # time loop + transposes inside libsmo: RCCL communicator of its own with the nccl backend (torch.distributed only carries the
-        # 128-byte unique id), the host-staged callback transport with gloo (ranks sharing a GPU in tests)
-        s = LibSlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device(), ckpt=ckpt)
-    except Exception as e:
-        err = e
-    if os.environ.get("SMO_BENCH_INJECT_FAILURE") == str(torch.distributed.get_rank()):     # test hook: this rank fails to construct
-        s, err = None, RuntimeError("injected construction failure")
-    bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else "cuda")
-    torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
-    if float(bad.item()) > 0:
-        del s
-        raise RuntimeError("slab solver construction failed on %s" % ("this rank: %r" % (err,) if err is not None else "another rank"))
+    # first all-to-all: every rank reports, and all raise together.  Two product paths are tried in turn, both HIP + RCCL:
+    #   1. time loop + transposes inside libsmo on its own RCCL communicator (torch.distributed only carries the 128-byte unique id;
+    #      with gloo — ranks sharing a GPU in tests — the host-staged callback transport)
+    #   2. the Python loop over the phase-level entry with torch.distributed's all_to_all_single (round 1's path), should the
+    #      library's communicator not come up on this node
+    from spheremanopt_amd.kdyn_slab import SlabKDyn
+    cdev = "cpu" if torch.distributed.get_backend() == "gloo" else "cuda"
+    s, last_err = None, None
+    for attempt, make in enumerate((lambda: LibSlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device(), ckpt=ckpt),
+                                    lambda: _PyLoop(SlabKDyn(N, Rm, dt, n_iters, "Final", device=torch.cuda.current_device())))):
+        if attempt == 1 and ckpt != 1:
+            break                                            # the Python loop has no windowed checkpoints with slabs
+        err = None
+        try:
+            s = make()
+        except Exception as e:
+            err = e
+        if attempt == 0 and os.environ.get("SMO_BENCH_INJECT_FAILURE") == str(torch.distributed.get_rank()):     # test hook
+            s, err = None, RuntimeError("injected construction failure")
+        if attempt == 0 and os.environ.get("SMO_BENCH_INJECT_LIB_FAILURE") == "1":                               # test hook: every rank
+            s, err = None, RuntimeError("injected failure of the in-library communicator")
+        if attempt == 1 and os.environ.get("SMO_BENCH_INJECT_FAILURE") is not None:
+            s, err = None, RuntimeError("injected construction failure")
+        bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=cdev)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if float(bad.item()) == 0:
+            break
+        s = None
+        last_err = err if err is not None else RuntimeError("slab solver construction failed on another rank")
+        sys.stderr.write("rank %d: slab solver path %d failed (%r)\n" % (torch.distributed.get_rank(), attempt, last_err))
+        torch.cuda.empty_cache()
+    if s is None:
+        raise RuntimeError("slab solver construction failed: %r" % (last_err,))
     Bl = s.local_slab(kdyn.synthetic_field(G, 1)); Ul = s.local_slab(kdyn.synthetic_field(G, 2))
     out = [torch.empty_like(Bl), torch.empty_like(Ul)]
     # warm-up passes time every kernel class (breakdown); the timed region records HIP events only around the dominant one, as on one GPU
@@ -310,9 +338,9 @@ def bench_kdyn_slab(a, torch, rank, world):
            "grid": [G, G, G], "n_iters": n_iters, "J": J, "stack_GB_per_gpu": s.ctx.stack_bytes / 1e9,
            "slab_J_matches_single_gpu": bool(abs(J - float(J_single[0].item())) <= 1e-9 * abs(float(J_single[0].item()))),
            "J_single_gpu": float(J_single[0].item()),
-           "parallelism": "slab x%d (kx / z decomposition; time loop and all-to-all transposes between the z and y passes inside libsmo, "
-                          "transport %s; %d field-group exchanges per step pair, %d pipelined z chunks)"
-                          % (world, "RCCL grouped send/recv" if s.transport == "rccl" else "callback (host-staged, test only)",
+           "parallelism": "slab x%d (kx / z decomposition; all-to-all transposes between the z and y passes, transport %s; "
+                          "%d field-group exchanges per step pair, %d pipelined z chunks)"
+                          % (world, {"rccl": "RCCL grouped send/recv", "callback": "callback (host-staged, test only)"}.get(s.transport, s.transport),
                              s.exchanges_per_step_pair, s.K),
            "transport": s.transport,
            "exchange_MB_sent_per_gpu_per_step_pair": s.exchanges_per_step_pair * _slab_elems(N, world) * 16 / 1e6 * (world - 1) / world,

@@ -1,7 +1,8 @@
 // LDS-staged Stockham autosort FFT for gfx950, complex128.
 //
-// A length-L transform is a chain of decimation-in-frequency Stockham stages of radix [8, then] 4, then 2, then 3
-// (L = 4^a 2^b 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..384 incl. 36 = 4*3*3 for Npts = 24).  Stage invariant n*s == L:
+// A length-L transform is a chain of decimation-in-frequency Stockham stages of radix [8, then] 4, then 2, then 5, then 3
+// (L = 4^a 2^b 5^d 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..480 incl. 36 = 4*3*3 for Npts = 24 and 30..480 = 3 * Npts/2
+// for Npts = 20, 40, 80, 160, 320).  Stage invariant n*s == L:
 //     y[q + s*(R*p + j)] = w_n^{p*j} * sum_k x[q + s*(p + k*n/R)] * w_R^{j*k},  0 <= p < n/R, 0 <= q < s
 // so (i) the R inputs of consecutive butterflies are consecutive 16-byte elements (conflict-free ds_read_b128 /
 // coalesced global loads) and (ii) in the last stage p == 0: no twiddles, outputs of consecutive butterflies
@@ -19,13 +20,14 @@ namespace smo {
 #ifndef SMO_FFT_MAX_RADIX
 #define SMO_FFT_MAX_RADIX 4
 #endif
-constexpr __host__ __device__ int radix_of(int n) {
-    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : 3));
+constexpr __host__ __device__ int radix_of(int n) {      // 5 before 3: a length with a factor 3 (every 3/2-dealiased grid) ends on radix 3
+    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : ((n % 5 == 0) ? 5 : 3)));
 }
 constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + stage_count(n / radix_of(n)); }
 constexpr bool fft_length_ok(int n) {
     while (n % 4 == 0) n /= 4;
     if (n % 2 == 0) n /= 2;
+    while (n % 5 == 0) n /= 5;
     while (n % 3 == 0) n /= 3;
     return n == 1;
 }
@@ -48,6 +50,18 @@ template <bool INV> struct Butterfly<3, INV> {
         cplx d = S60 * (v[1] - v[2]);
         cplx r = rot90<INV>(d);
         v[0] = v[0] + t; v[1] = m + r; v[2] = m - r;
+    }
+};
+template <bool INV> struct Butterfly<5, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[5]) {
+        const double C1 = 0.30901699437494742410229341718282, C2 = -0.80901699437494742410229341718282;      // cos(2 pi/5), cos(4 pi/5)
+        const double S1 = 0.95105651629515357211643933337938, S2 = 0.58778525229247312916870595463907;       // sin(2 pi/5), sin(4 pi/5)
+        const cplx t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+        const cplx a1 = mk(v[0].re + C1 * t1.re + C2 * t2.re, v[0].im + C1 * t1.im + C2 * t2.im);
+        const cplx a2 = mk(v[0].re + C2 * t1.re + C1 * t2.re, v[0].im + C2 * t1.im + C1 * t2.im);
+        const cplx r1 = rot90<INV>(mk(S1 * t3.re + S2 * t4.re, S1 * t3.im + S2 * t4.im));
+        const cplx r2 = rot90<INV>(mk(S2 * t3.re - S1 * t4.re, S2 * t3.im - S1 * t4.im));
+        v[0] = v[0] + t1 + t2; v[1] = a1 + r1; v[2] = a2 + r2; v[3] = a2 - r2; v[4] = a1 - r1;
     }
 };
 template <bool INV> struct Butterfly<4, INV> {

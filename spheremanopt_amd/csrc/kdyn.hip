@@ -661,8 +661,10 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        if (!(N == 8 || N == 16 || N == 24 || N == 32 || N == 48 || N == 64 || N == 96 || N == 128 || N == 192 || N == 256)) {
-            set_error("KDYN: npts must be one of 8,16,24,32,48,64,96,128,192,256 (got %d)", N);
+        static const int sizes[] = {8, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320};
+        if (std::find(std::begin(sizes), std::end(sizes), N) == std::end(sizes)) {
+            // the transform lengths G = 3N/2 are compile-time instantiations (factors 2, 3 and 5); the reference, through FFTW, takes any even Npts
+            set_error("KDYN: npts must be one of 8,16,20,24,32,40,48,64,80,96,128,160,192,256,320 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
         if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
@@ -756,6 +758,11 @@ public:
         switch (g.G) {
             case 12: return f(std::integral_constant<int, 12>());
             case 24: return f(std::integral_constant<int, 24>());
+            case 30: return f(std::integral_constant<int, 30>());      // Npts = 20, 40, 80, 160, 320: one radix-5 stage
+            case 60: return f(std::integral_constant<int, 60>());
+            case 120: return f(std::integral_constant<int, 120>());
+            case 240: return f(std::integral_constant<int, 240>());
+            case 480: return f(std::integral_constant<int, 480>());
             case 36: return f(std::integral_constant<int, 36>());      // Npts = 24, the reference script's default
             case 72: return f(std::integral_constant<int, 72>());
             case 144: return f(std::integral_constant<int, 144>());

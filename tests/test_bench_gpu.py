@@ -93,6 +93,17 @@ def test_failure_on_one_rank_is_agreed_on_by_all():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "slab_path_error" in d["config"] and "replicas" in d["config"]["parallelism"]
 
 
+def test_second_slab_path_when_the_library_communicator_fails():
+    """Should libsmo's own communicator not come up (here: injected on every rank), the slab decomposition still runs — Python loop over
+    the phase-level entry with torch.distributed's all-to-all — before anything falls back to replicas."""
+    p, lines = _launch(["--gpus", "2", "--npts", "32", "--iters", "20", "--steps", "1", "--warmup", "1", "--no-secondary"],
+                       extra_env={"SMO_BENCH_INJECT_LIB_FAILURE": "1"}, port=29747)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "Python loop" in d["config"]["transport"]
+    assert d["config"]["slab_J_matches_single_gpu"] and "slab_path_error" not in d["config"]
+
+
 def test_two_rank_line_reports_slab_and_independent_gradients():
     """The N>1 launch of the contract (torch.distributed.run, one rank per process) on the one GPU of the test box: ranks share cuda:0
     and exchange through gloo.  One JSON line from rank 0, strong scaling, slab J equal to the single-GPU J, plus the exchange-free figure."""

@@ -29,12 +29,14 @@ def _fields(G, dirty=False):
     return B, U
 
 
-_SMALL = [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True)]
+_SMALL = [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True),
+          (20, 3, 1e-2, True), (40, 3, 1e-3, True)]         # G = 30, 60: lengths with a radix-5 stage
 _ALL4 = [(c, a) for c in ("Final", "Integrated") for a in ("Discrete", "Continuous")]
 # every cost / adjoint combination inline up to 64^3; the default one also at 96^3 and 128^3 (the other three at 128^3 — and 256^3 — are
 # compared with the committed oracle fixtures below: 50 / 2 steps of all four, test_config4_fixture / test_config5_fixture)
 _CASES = [(N, n, dt, d, c, a) for (N, n, dt, d) in _SMALL for (c, a) in _ALL4] + \
-         [(96, 1, 1e-3, False, "Final", "Discrete"), (96, 1, 1e-3, True, "Integrated", "Continuous"), (128, 2, 1e-3, False, "Final", "Discrete")]
+         [(96, 1, 1e-3, False, "Final", "Discrete"), (96, 1, 1e-3, True, "Integrated", "Continuous"), (128, 2, 1e-3, False, "Final", "Discrete"),
+          (80, 2, 1e-3, True, "Final", "Discrete"), (80, 2, 1e-3, False, "Integrated", "Continuous"), (160, 1, 1e-3, True, "Final", "Discrete")]
 
 
 @pytest.mark.parametrize("N,n,dt,dirty,cost,adj", _CASES)
@@ -173,11 +175,11 @@ def test_size_independent_properties():
     dom.drop_contexts()
 
 
-@pytest.mark.parametrize("N", [32, 192, 256])
+@pytest.mark.parametrize("N", [32, 192, 256, 160, 320])
 def test_known_answer_single_mode_decay(N):
     """U = 0, B = (0, cos 3x, 0): every CNAB1 step multiplies the mode by (1/dt - 9/2Rm)/(1/dt + 9/2Rm) — an answer that does not
     come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost.  N = 192 (G = 288 = 4*4*2*3*3): a size whose
-    oracle run would take minutes is checked through this closed form; N = 256 (G = 384): the north-star grid's kernel instantiations."""
+    oracle run would take minutes is checked through this closed form; N = 256 (G = 384): the north-star grid's kernel instantiations; N = 160, 320 (G = 240, 480 = 4*4*[2*]5*3): the radix-5 sizes."""
     n, dt, Rm = 9, 1e-2, 1.3
     dom = kdyn.KDynDomain(N)
     G = dom.G
@@ -203,7 +205,7 @@ def test_known_answer_single_mode_decay(N):
 
 def test_errors():
     with pytest.raises(_capi.SmoError):
-        _capi.Context(_capi.SMO_KDYN, 20, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size
+        _capi.Context(_capi.SMO_KDYN, 28, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size (G = 42 has a factor 7)
     ctx = _capi.Context(_capi.SMO_KDYN, 8, (0., 2 * np.pi), 1e-3, 2, 1.0)
     with pytest.raises(_capi.SmoError) as e:
         ctx.adjoint(None)
