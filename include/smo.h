@@ -98,7 +98,8 @@ int smo_vec_len(const smo_ctx* ctx, size_t* len);               /* doubles per c
 int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by the snapshot stack(s) */
 /* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: KDYN: bytes of the y-side stack kept by the forward
  * solve so that the adjoint skips the z/y passes of every snapshot (0 if not in use); SHB23: how many calls fell back from the
- * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU). */
+ * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU);  key 2 (KDYN): number of
+ * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch). */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */

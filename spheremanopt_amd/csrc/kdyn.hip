@@ -680,6 +680,8 @@ public:
         // natural stride 16*G*Gzl (a multiple of 64 KB at every supported size) they all fall on the same HBM channel: measured
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
+        { const char* e = getenv("SMO_KD_GRAPH"); if (e) graph_mode = atoi(e); }
+        { const char* e = getenv("SMO_KD_GRAPH_MAXG"); if (e) graph_max_g = atoi(e); }
         { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
         if (ty_pad % 8 != 0) { set_error("KDYN: SMO_KD_TYPAD must be a multiple of 8 elements (one 128-byte line)"); return SMO_ERR_ARG; }
         g.typ = (size_t)g.G * g.Gzl + ty_pad;
@@ -983,6 +985,7 @@ public:
     ~KDyn() override {
         (void)hipSetDevice(cfg.device);
         if (stream) (void)hipStreamSynchronize(stream);
+        drop_graphs();
         if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
         if (ev_main) (void)hipEventDestroy(ev_main);
         for (auto* v : {&ev_in, &ev_ph, &ev_out}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
@@ -1098,16 +1101,67 @@ public:
         if (K != 1 && !exchanging()) { set_error("%s: the z slab is cut into %d chunks (phase-level use only)", who, K); return SMO_ERR_STATE; }
         return need_buffers();
     }
-    int forward_dev(const double* const* X, double* J) override {
-        SMO_TRY(loop_ok("smo_forward"));
-        have_forward = false;
+    // ---- HIP graphs for the launch-bound sizes ----------------------------------------------------------------------------
+    // A 24^3 solve (the reference script's default) is 2000 steps x 4 kernels of ~2 us of work each: 4.8 us per launch measured.  For
+    // such grids on one GPU the whole forward solve and the whole adjoint sweep are captured ONCE as HIP graphs (the stack addresses
+    // never change; the caller's vectors are copied to / from fixed buffers so that the graphs are independent of them) and replayed
+    // by every later call.  Same kernels in the same order: results are bit-identical with the launch-by-launch path (SMO_KD_GRAPH=0).
+    // Measured (tools/time_small_grid.py, profiles/r02_small_grid_graph.jsonl): 77.0 -> 68.7 ms per gradient at 24^3 (4.8 -> 4.3 us per
+    // kernel: what remains is the GPU-side hand-over between dependent kernels, not the host), no gain from 32^3 up, +75 ms for the
+    // capture at the first call — hence on by default only up to G = 36.  Off while kernel timing is on, with slabs, chunks or
+    // checkpoint windows.
+    int graph_mode = -1, graph_max_g = 36;       // SMO_KD_GRAPH: -1 (default) = grids up to graph_max_g (SMO_KD_GRAPH_MAXG), 0 = never, 1 = always
+    bool graph_broken = false;
+    hipGraphExec_t gx_fwd = nullptr, gx_adj[2] = {nullptr, nullptr};
+    struct Flags { int zf, za; bool cont; } fl_fwd{}, fl_adj[2]{};
+    double *d_xin[2] = {nullptr, nullptr}, *d_gout[2] = {nullptr, nullptr};
+    long long graph_replays = 0;
+    bool use_graph() const {
+        if (graph_broken || graph_mode == 0 || timing.on || cfg.world != 1 || force_exchange || K != 1 || ck != 1) return false;
+        return graph_mode == 1 || g.G <= graph_max_g;
+    }
+    template <class F> int run_graph(hipGraphExec_t* gx, Flags* after, F enqueue) {
+        if (!*gx) {
+            hipGraph_t graph = nullptr;
+            SMO_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue();
+            const hipError_t e = hipStreamEndCapture(stream, &graph);
+            if (rc != SMO_OK || e != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                graph_broken = true;                     // this context goes on launch by launch
+                return rc != SMO_OK ? rc : enqueue();
+            }
+            const hipError_t ei = hipGraphInstantiate(gx, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) { *gx = nullptr; (void)hipGetLastError(); graph_broken = true; return enqueue(); }
+            *after = Flags{zs_ready_fwd, zs_ready_adj, adj_cont};
+        }
+        SMO_HIP(hipGraphLaunch(*gx, stream));
+        zs_ready_fwd = after->zf; zs_ready_adj = after->za; adj_cont = after->cont;      // what the enqueueing code leaves behind
+        ++graph_replays;
+        return SMO_OK;
+    }
+    int graph_buffers() {
+        for (int c = 0; c < 2; ++c) {
+            if (!d_xin[c]) SMO_TRY(pool.alloc(&d_xin[c], n_grid));
+            if (!d_gout[c]) SMO_TRY(pool.alloc(&d_gout[c], n_grid));
+        }
+        return SMO_OK;
+    }
+    void drop_graphs() {
+        for (hipGraphExec_t* x : {&gx_fwd, &gx_adj[0], &gx_adj[1]})
+            if (*x) { (void)hipGraphExecDestroy(*x); *x = nullptr; }
+    }
+
+    // everything of a forward solve that is a kernel launch (the partial sums of J stay in d_part)
+    int fwd_enqueue(const double* B, const double* U) {
         const int N = cfg.n_iters;
-        // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver, SURVEY A.0-4)
-        SMO_TRY(grid_to_coeff(X[1], d_G));
-        SMO_TRY(coeff_to_grid(d_G, false, nullptr));
-        SMO_TRY(grid_to_coeff(X[0], snap(0)));
-        double Jacc = 0.0, E = 0.0;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
+        // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver, SURVEY A.0-4)
+        SMO_TRY(grid_to_coeff(U, d_G));
+        SMO_TRY(coeff_to_grid(d_G, false, nullptr));
+        SMO_TRY(grid_to_coeff(B, snap(0)));
         for (int n = 0; n < N; ++n) {
             if (integ) {                                   // <B_n,B_n> partial sums stay on the device until the end of the solve
                 ScopedTimer t(timing, k_misc, stream);
@@ -1115,22 +1169,31 @@ public:
             }
             SMO_TRY(step_fwd(n, true));
         }
-        scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
-        if (integ) {
-            {
-                ScopedTimer t(timing, k_misc, stream);
-                hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(N), d_part + (size_t)N * NPART, g);
-            }
-            SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, (size_t)(N + 1) * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
-            SMO_HIP(hipStreamSynchronize(stream));
-            for (int n = 0; n <= N; ++n) {
-                double e = 0.0;
-                for (int i = 0; i < NPART; ++i) e += h_part[(size_t)n * NPART + i];
-                Jacc += cfg.dt * e;
-            }
+        ScopedTimer t(timing, k_misc, stream);
+        hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(N), d_part + (integ ? (size_t)N * NPART : 0), g);
+        return SMO_OK;
+    }
+    int forward_dev(const double* const* X, double* J) override {
+        SMO_TRY(loop_ok("smo_forward"));
+        have_forward = false;
+        const int N = cfg.n_iters;
+        const bool integ = cfg.cost == SMO_COST_INTEGRATED;
+        if (use_graph()) {
+            SMO_TRY(graph_buffers());
+            for (int c = 0; c < 2; ++c) SMO_HIP(hipMemcpyAsync(d_xin[c], X[c], n_grid * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SMO_TRY(run_graph(&gx_fwd, &fl_fwd, [&]() { return fwd_enqueue(d_xin[0], d_xin[1]); }));
         } else {
-            SMO_TRY(energy(snap(N), &E));
-            Jacc = E;
+            SMO_TRY(fwd_enqueue(X[0], X[1]));
+        }
+        scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
+        const size_t rows = integ ? (size_t)N + 1 : 1;
+        SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, rows * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        double Jacc = 0.0;
+        for (size_t n = 0; n < rows; ++n) {
+            double e = 0.0;
+            for (int i = 0; i < NPART; ++i) e += h_part[n * NPART + i];
+            Jacc += integ ? cfg.dt * e : e;
         }
         SMO_HIP(hipGetLastError());
         SMO_TRY(allreduce(&Jacc, 1));                        // slabs: every rank holds its share of the spectral sum
@@ -1141,8 +1204,7 @@ public:
         return SMO_OK;
     }
 
-    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
-        SMO_TRY(loop_ok("smo_adjoint"));
+    int adj_enqueue(int adjoint_type, double* gB, double* gU) {
         const int N = cfg.n_iters;
         const bool cont = adjoint_type == SMO_ADJ_CONTINUOUS;
         SMO_TRY(ensure(N));
@@ -1154,10 +1216,21 @@ public:
             SMO_TRY(stage(ST_ADJ, idx, adj_groups(idx), 1));
             SMO_TRY(adj_C(idx));
         }
-        SMO_TRY(coeff_to_grid(d_G, !cont, grad[0]));
+        SMO_TRY(coeff_to_grid(d_G, !cont, gB));
         for (int k = 0; k < K; ++k) { SMO_TRY(nu_B(k)); SMO_TRY(exchange(false, 1, k, stream)); }
         SMO_TRY(nu_C());
-        SMO_TRY(coeff_to_grid(d_nu, false, grad[1]));
+        return coeff_to_grid(d_nu, false, gU);
+    }
+    int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
+        SMO_TRY(loop_ok("smo_adjoint"));
+        if (use_graph()) {
+            SMO_TRY(graph_buffers());
+            const int a = adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0;
+            SMO_TRY(run_graph(&gx_adj[a], &fl_adj[a], [&]() { return adj_enqueue(adjoint_type, d_gout[0], d_gout[1]); }));
+            for (int c = 0; c < 2; ++c) SMO_HIP(hipMemcpyAsync(grad[c], d_gout[c], n_grid * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        } else {
+            SMO_TRY(adj_enqueue(adjoint_type, grad[0], grad[1]));
+        }
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
         if (cstream) SMO_HIP(hipStreamSynchronize(cstream));
@@ -1176,6 +1249,7 @@ public:
 
     double info(int key) const override {
         if (key == 0) return (double)ck;
+        if (key == 2) return (double)graph_replays;
         return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 
@@ -1192,6 +1266,7 @@ public:
         if (op == SMO_KD_SET_BUFFERS) {
             if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
             zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1); zs_ready_fwd = zs_ready_adj = -1;
+            drop_graphs();
             return SMO_OK;
         }
         if (op == SMO_KD_EXCHANGE_ELEMS) { if (!out) return SMO_ERR_ARG; *out = (double)(tzb * cfg.world); return SMO_OK; }

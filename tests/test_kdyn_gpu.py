@@ -340,3 +340,54 @@ def test_layout_and_fusion_knobs_are_bit_identical_at_G384(monkeypatch, knob, of
     a, b = res
     assert a[0] == b[0] and np.array_equal(a[2], b[2])
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+
+
+@pytest.mark.parametrize("cost", ["Final", "Integrated"])
+def test_hip_graph_replay_is_bit_identical(monkeypatch, cost):
+    """Small grids on one GPU run the whole forward solve / adjoint sweep as ONE captured HIP graph (launch-bound: ~2 us of work per
+    kernel).  Same kernels, same order: every number must equal the launch-by-launch path (SMO_KD_GRAPH=0), also on replays with other
+    input vectors, for both adjoint types, and with device-resident vectors."""
+    from spheremanopt_amd.devvec import to_device
+    N, n = 24, 40                                          # the reference script's default grid
+    G = 3 * N // 2
+    X1 = [kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)]
+    X2 = [kdyn.synthetic_field(G, 5) + 0.1, kdyn.synthetic_field(G, 6)]
+    res = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("SMO_KD_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("SMO_KD_GRAPH", mode)
+        dom = kdyn.KDynDomain(N)
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        out = []
+        for X in (X1, X2, X1, to_device(X2)):
+            for adj in ("Discrete", "Continuous"):
+                args = [dom, 1., 1e-3, n, n, buf, cost, adj]
+                J = kdyn.FWD_Solve_IVP_Lin(X, *args)
+                g = kdyn.ADJ_Solve_IVP_Lin(X, *args)
+                g = [v.numpy() if hasattr(v, "numpy") else v for v in g]
+                out.append((J, g, buf["B_fwd"][:, :, :, n // 2].copy()))
+        replays = dom.context(1., 1e-3, n, cost).get(2)
+        assert (replays == 0) if mode == "0" else (replays == 16), replays       # 8 forward + 8 adjoint calls, captured at the first of each kind
+        res[mode] = out
+        dom.drop_contexts()
+    for a, b in zip(res["0"], res[None]):
+        assert a[0] == b[0] and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+    assert res[None][0][0] != res[None][2][0] and res[None][0][0] == res[None][4][0]      # the replays saw their own inputs
+
+
+def test_hip_graph_is_off_where_it_does_not_apply(monkeypatch):
+    dom = kdyn.KDynDomain(128)                             # G = 192 > SMO_KD_GRAPH_MAXG: launch by launch
+    B, U = _fields(dom.G)
+    ctx = dom.context(1., 1e-3, 2, "Final")
+    ctx.forward([B, U]); ctx.adjoint(None)
+    assert ctx.get(2) == 0
+    dom.drop_contexts()
+    small = kdyn.KDynDomain(16, ckpt=2)                    # checkpoint windows: recomputation is decided on the host
+    ctx = small.context(1., 1e-3, 6, "Final")
+    B, U = _fields(small.G)
+    ctx.forward([B, U]); ctx.adjoint(None)
+    assert ctx.get(2) == 0
+    ctx.timing_enable(True)
+    small.drop_contexts()
