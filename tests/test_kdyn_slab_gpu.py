@@ -272,3 +272,32 @@ def test_bench_size_slabs_agree_with_the_single_gpu_path(tmp_path, N, world, chu
             assert np.linalg.norm(r[name][idx] - ref) <= 1e-6 * np.linalg.norm(ref)
             nrm = float(gold["Final_Discrete_%s_norm" % name])
             assert abs(np.linalg.norm(r[name]) - nrm) <= 1e-6 * nrm
+
+
+def test_communicator_errors():
+    """world > 1 without a communicator: the loop entry points refuse (the phase-level entry still works); a single-slab context has
+    nothing to exchange; smo_comm_get reports the pipeline."""
+    import ctypes as C
+    from spheremanopt_amd import _capi
+    ctx = _capi.Context(_capi.SMO_KDYN, 16, (0., 2 * np.pi), 1e-3, 2, 1.0, rank=1, world=2)
+    x = np.zeros(ctx.vec_len)
+    with pytest.raises(_capi.SmoError) as e:
+        ctx.forward([x, x])
+    assert e.value.code == 4 and "smo_comm_init" in str(e.value)
+    assert ctx.comm_get(0) == 1 and ctx.comm_get(2) == 0
+    one = _capi.Context(_capi.SMO_KDYN, 16, (0., 2 * np.pi), 1e-3, 2, 1.0)
+    with pytest.raises(_capi.SmoError) as e:
+        one.comm_init(b"\0" * 128)
+    assert e.value.code == 4
+    with pytest.raises(ValueError):
+        ctx.comm_init(b"short")
+    # a transport whose all-to-all raises: the call fails with an error code instead of unwinding through the C frames
+    def boom(src, dst, nbytes, stream):
+        raise RuntimeError("wire down")
+    def ared(vals, n):
+        for i in range(n):
+            vals[i] = 2.0 * vals[i]          # pretend the other rank decided the same
+    ctx.comm_set_transport(boom, ared)
+    with pytest.raises(_capi.SmoError) as e:
+        ctx.forward([x, x])
+    assert "transport failed" in str(e.value) and isinstance(ctx._transport_error, RuntimeError)
