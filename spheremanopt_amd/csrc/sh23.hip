@@ -36,7 +36,7 @@ __device__ __forceinline__ void pack_mode(cplx* P, int k, cplx X, cplx tw2k /* e
 template <int NH>
 __device__ __forceinline__ cplx unpack_mode(const cplx* P, int k, cplx tw2k) {
     cplx Zk = P[k];
-    cplx Zm = conj(P[(NH - k) & (NH - 1)]);
+    cplx Zm = conj(P[k == 0 ? 0 : NH - k]);
     cplx Ev = 0.5 * (Zk + Zm);
     cplx Od = mul_mi(0.5 * (Zk - Zm));
     return Ev + Od * tw2k;
@@ -224,10 +224,8 @@ public:
         NH = cfg.npts;
         G = 2 * NH;
         NC = (cfg.npts - 1) / 2 + 1;
-        if (NH < 16 || NH > 1024 || (NH & (NH - 1)) != 0) {
-            set_error("SH23: npts must be a power of two in [16, 1024], got %d", cfg.npts);
-            return SMO_ERR_UNSUPPORTED;
-        }
+        // the transform length is a compile-time instantiation: 2^k, 3*2^k, 5*2^k, 15*2^k in [16, 1024] (the reference, through FFTW, takes any even Npts)
+        if (dispatch([](auto) { return SMO_OK; }) != SMO_OK) return SMO_ERR_UNSUPPORTED;
         n_comp = 1;
         vec_len = (size_t)G;
         snapshot_doubles = 2 * (size_t)NC;
@@ -256,15 +254,15 @@ public:
 
     template <class F> int dispatch(F f) {
         switch (NH) {
-            case 16: return f(std::integral_constant<int, 16>());
-            case 32: return f(std::integral_constant<int, 32>());
-            case 64: return f(std::integral_constant<int, 64>());
-            case 128: return f(std::integral_constant<int, 128>());
-            case 256: return f(std::integral_constant<int, 256>());
-            case 512: return f(std::integral_constant<int, 512>());
+#define SMO_SH_CASE(n) case n: return f(std::integral_constant<int, n>());
+            SMO_SH_CASE(16) SMO_SH_CASE(32) SMO_SH_CASE(64) SMO_SH_CASE(128) SMO_SH_CASE(256) SMO_SH_CASE(512)
+            SMO_SH_CASE(24) SMO_SH_CASE(48) SMO_SH_CASE(96) SMO_SH_CASE(192) SMO_SH_CASE(384) SMO_SH_CASE(768)          // 3 * 2^k
+            SMO_SH_CASE(20) SMO_SH_CASE(40) SMO_SH_CASE(80) SMO_SH_CASE(160) SMO_SH_CASE(320) SMO_SH_CASE(640)          // 5 * 2^k
+            SMO_SH_CASE(60) SMO_SH_CASE(120) SMO_SH_CASE(240) SMO_SH_CASE(480) SMO_SH_CASE(960)                         // 15 * 2^k
+#undef SMO_SH_CASE
             case 1024: return f(std::integral_constant<int, 1024>());
         }
-        set_error("SH23: unsupported npts %d", NH);
+        set_error("SH23: npts must be 2^k, 3*2^k, 5*2^k or 15*2^k in [16, 1024] (got %d)", NH);
         return SMO_ERR_UNSUPPORTED;
     }
 

@@ -164,7 +164,10 @@ template <int NH> __device__ void dct3(DctWork<NH>& w, const double* x, double* 
 
 // out[n] = sum_j M[j][n] v[j]   (M row j contiguous in n: coalesced 16-byte loads; v, out, part in LDS)
 __device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
-    const int npairs = N >> 1, ngrp = (NT / npairs < N) ? NT / npairs : N, cols = N / ngrp;    // N = 32: 32 groups, half the block idles
+    const int npairs = N >> 1;
+    int ngrp = (NT / npairs < N) ? NT / npairs : N;              // N = 32: 32 groups, half the block idles
+    while (N % ngrp != 0 || ngrp * N > 2 * NT) --ngrp;           // column groups of equal size whose partial sums fit `part` (N = 3 * 2^k)
+    const int cols = N / ngrp;
     const int np = tid % npairs, jg = tid / npairs;
     const double2* M2 = reinterpret_cast<const double2*>(M);
     if (jg < ngrp) {
@@ -539,8 +542,8 @@ public:
         Nc = cfg.npts;
         N = cnts ? 2 * Nc : Nc;                    // "Continuous": npts modes, dealias 2 => vectors live on the 2*npts Gauss grid
         NH = N / 2;
-        if (N < 64 || N > 1024 || (N & (N - 1)) != 0) {
-            set_error("SHB23: the grid length must be a power of two in [64, 1024], got %d", N);
+        if (dispatch([](auto) { return SMO_OK; }) != SMO_OK) {      // compile-time instantiations: 2^k and 3 * 2^k
+            set_error("SHB23: the grid length must be 2^k or 3*2^k in [64, 1024], got %d", N);
             return SMO_ERR_UNSUPPORTED;
         }
         Lz = cfg.x1 - cfg.x0;
@@ -585,7 +588,10 @@ public:
         SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
         // latency mode: a single problem is spread over KC = N^2/8192 CUs (64 KB of operator rows per CU); SMO_SHB_CLUSTER=0 disables
         const char* env = getenv("SMO_SHB_CLUSTER");
-        if (cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) KC = Nc * Nc / 8192;    // N = 1024 would not fit the LDS
+        if (cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) {    // N = 1024 would not fit the LDS
+            KC = (Nc * Nc + 8191) / 8192;                      // members: at most 64 KB of operator rows each ...
+            while (Nc % KC != 0) ++KC;                         // ... and the same number of rows (Nc = 384: 24 members of 16 rows)
+        }
         SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * Nc));
         SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 2));          // arrival counters | error flag | spin cap
         d_clerr = d_clcnt + cfg.batch;
@@ -601,6 +607,10 @@ public:
     template <class F> int dispatch(F f) {
         switch (NH) {
             case 32: return f(std::integral_constant<int, 32>());
+            case 48: return f(std::integral_constant<int, 48>());       // N = 96, 192, 384, 768: one radix-3 stage
+            case 96: return f(std::integral_constant<int, 96>());
+            case 192: return f(std::integral_constant<int, 192>());
+            case 384: return f(std::integral_constant<int, 384>());
             case 64: return f(std::integral_constant<int, 64>());
             case 128: return f(std::integral_constant<int, 128>());
             case 256: return f(std::integral_constant<int, 256>());

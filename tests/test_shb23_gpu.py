@@ -31,7 +31,7 @@ def test_device_transforms_match_reference_helpers():
     assert rel(shb23.transformInverse(shb23.transform(v, dom), dom), v) < 1e-13
 
 
-@pytest.mark.parametrize("N,n", [(64, 30), (128, 100), (256, 40), (1024, 10)])
+@pytest.mark.parametrize("N,n", [(64, 30), (128, 100), (256, 40), (1024, 10), (96, 40), (192, 60), (384, 40), (768, 12)])
 def test_forward_adjoint_vs_oracle(N, n):
     from oracle import shb23 as osh
     o = osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n)
@@ -91,7 +91,7 @@ def test_batch_and_errors():
 
 # ---- "Continuous" formulation (Npts modes, scale-2 grid vectors; FWD_Solve_SHB23.py:398-523, 685-794) --------------------------
 
-@pytest.mark.parametrize("N,n", [(32, 30), (64, 100), (256, 60), (512, 10)])
+@pytest.mark.parametrize("N,n", [(32, 30), (64, 100), (256, 60), (512, 10), (48, 40), (192, 30), (384, 10)])
 def test_continuous_forward_adjoint_vs_oracle(N, n):
     from oracle import shb23 as osh
     o = osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n)
