@@ -1118,6 +1118,7 @@ public:
     long long graph_replays = 0;
     bool use_graph() const {
         if (graph_broken || graph_mode == 0 || timing.on || cfg.world != 1 || force_exchange || K != 1 || ck != 1) return false;
+        if (cfg.n_iters > 8192) return false;                 // a graph holds ~4 nodes per step: keep its instantiation in the tens of milliseconds
         return graph_mode == 1 || g.G <= graph_max_g;
     }
     template <class F> int run_graph(hipGraphExec_t* gx, Flags* after, F enqueue) {
