@@ -525,7 +525,16 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 // tiles of a line are given to workgroups b, b+8, ..., which the dispatcher places on the same XCD at about the same time: the
 // rest of every line is then served by that XCD's L2 instead of being fetched from HBM again (speed only, never correctness).
 template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = tiles per 128-byte line of the spectra (0/1: no remapping)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
+#ifndef SMO_X_WAVES
+#define SMO_X_WAVES 3
+#endif
+#ifndef SMO_X_FWD_NT
+#define SMO_X_FWD_NT 256
+#endif
+#ifndef SMO_X_ADJ_NT
+#define SMO_X_ADJ_NT 192
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
     __shared__ cplx buf[XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ)>::ELEMS];
@@ -783,8 +792,10 @@ public:
         static constexpr int H = (L > 192) ? 2 : 1;
         static constexpr int ZNBT = 2 / H, ZNT = 256;          // z passes: row triples per workgroup (6 / 3 FFTs: 18 KB of LDS => 8 workgroups per CU)
         static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
-        static constexpr int XT = 8 / H, XNT = 192;            // forward x pass: (y,z) points per workgroup (12 / 6 FFTs); 128-B runs at G=192
-        static constexpr int XTA = 4 / H, XANT = 192;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
+        // forward x pass: (y,z) points per workgroup (12 / 6 FFTs; 128-B runs at G = 192).  256 threads: one middle-section item per thread
+        // (HP * G/3 = 256), 102-105 VGPRs => 4 waves per SIMD = 16 per CU (192 threads: 148-154 VGPRs, 12 per CU): -5..-7 % on this kernel
+        static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
+        static constexpr int XTA = 4 / H, XANT = SMO_X_ADJ_NT;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
 
