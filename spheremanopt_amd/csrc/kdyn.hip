@@ -528,6 +528,9 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 #ifndef SMO_X_WAVES
 #define SMO_X_WAVES 3
 #endif
+#ifndef SMO_Y_ZT
+#define SMO_Y_ZT 8        // y pass: z columns per workgroup = one 128-byte line; 25 KB (G = 192) / 49 KB (G = 384) of LDS => 5 / 3 workgroups per CU
+#endif
 #ifndef SMO_X_FWD_NT
 #define SMO_X_FWD_NT 256
 #endif
@@ -791,7 +794,7 @@ public:
     template <int L> struct Shape {
         static constexpr int H = (L > 192) ? 2 : 1;
         static constexpr int ZNBT = 2 / H, ZNT = 256;          // z passes: row triples per workgroup (6 / 3 FFTs: 18 KB of LDS => 8 workgroups per CU)
-        static constexpr int YZT = 16 / H, YNT = 256;          // y pass: z columns per workgroup
+        static constexpr int YZT = SMO_Y_ZT, YNT = 256;          // y pass: z columns per workgroup
         // forward x pass: (y,z) points per workgroup (12 / 6 FFTs; 128-B runs at G = 192).  256 threads: one middle-section item per thread
         // (HP * G/3 = 256), 102-105 VGPRs => 4 waves per SIMD = 16 per CU (192 threads: 148-154 VGPRs, 12 per CU): -5..-7 % on this kernel
         static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
