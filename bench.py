@@ -207,7 +207,7 @@ def bench_pois(a, torch, rank, world):
     return steps, warm, el, 1, roof, cfg, None
 
 
-def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=2):
+def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=4):
     """Oracle timed on a bounded sample: `sample_steps` forward + adjoint steps at the full grid, scaled to n_iters."""
     from oracle.kdyn import KDynOracle
     o = KDynOracle(N, Rm=Rm, dt=dt, N_ITERS=sample_steps, workers=workers)
