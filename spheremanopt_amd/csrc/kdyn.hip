@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
 // x pass (strided, real <-> Hermitian half spectrum), two real lines per complex FFT, T flat (y,z) points per
 // workgroup.  Modes: spectrum -> grid; grid -> spectrum; fused  spectrum -> grid product(s) -> spectrum.
 // ---------------------------------------------------------------------------------------------------------
-enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3 };
+enum { X_TO_GRID = 0, X_FROM_GRID = 1, X_FUSED_FWD = 2, X_FUSED_ADJ = 3, X_FUSED_ADJ_SEQ = 4 };
 
 // Row padding of the x pass's LDS tile (complex elements).  Lanes run over the NB transforms first, then over consecutive positions:
 // element (b, pos) starts at bank group (pad * b + pos) mod 16, and a 64-lane 16-byte access is conflict-free when each of the 16
@@ -521,6 +521,142 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Adjoint x pass, field groups ONE AFTER THE OTHER through the tile buffer (X_FUSED_ADJ_SEQ).  The pass needs omega = curl G and B_f on
+// the grid at the same points; X_FUSED_ADJ transforms both at once (6 * HP transforms in the tile), which at a given LDS footprint halves
+// the (y,z) points per tile: 64-byte runs of the spectra at G = 192, 32-byte runs at G = 384 — and the access pattern itself then caps the
+// pass (tools/micro_gather.hip: a bare copy with that pattern reaches 5.1 / 3.6 TB/s, with runs twice as long 6.2 / 4.6).  Here omega
+// goes first: inverse transform, last radix-3 stage in registers, and its grid values STAY in registers (9 complex per item) while
+//   F1 = omega x U    is formed, transformed forward through the same buffer and stored, then
+//   B_f               is staged, transformed, and F2' = omega x B_f goes forward and is added to the running sum.
+// Same arithmetic per element as X_FUSED_ADJ, 3 * HP transforms in the tile => tiles of twice as many points (128 / 64-byte runs).
+// ---------------------------------------------------------------------------------------------------------
+template <int L, int T, int NT, class TW>
+__device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __restrict__ gridU, const Geom& g, cplx* buf, const TW tw,
+                                               const size_t i0, const int tid) {
+    constexpr int HP = T / 2, NB = 3 * HP, S3 = L / 3;
+    constexpr XLayout<L, NB, true> ix{};
+    constexpr int NITEM = S3 * 3 * HP;                         // stored modes of one field group = items of the staging / split loops
+    constexpr int SCNT = (NITEM + NT - 1) / NT;
+    constexpr int ICNT = (HP * S3 + NT - 1) / NT;              // middle-section items (j, p) per thread
+    static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
+    const size_t plane = (size_t)g.G * g.Gzl;
+    auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
+    auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
+
+    auto stage_in = [&](const cplx* src) {                     // spectra of one field group -> Hermitian-extended lines in the tile
+#pragma unroll
+        for (int i = 0; i < SCNT; ++i) {
+            const int t = tid + i * NT;
+            if (t >= NITEM) break;
+            const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
+            cplx X1 = mk(0, 0), X2 = mk(0, 0);
+            if (line_ok(p)) { const cplx* q = src + tx_off(c, kx, i0 + 2 * p, g); X1 = q[0]; X2 = q[1]; }
+            const int b = c * HP + p;
+            if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);
+            else {
+                buf[ix(b, kx)] = mk(X1.re - X2.im, X1.im + X2.re);
+                buf[ix(b, L - kx)] = mk(X1.re + X2.im, X2.re - X1.im);
+            }
+        }
+        __syncthreads();
+        fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
+            return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];
+        });
+    };
+    auto read_win = [&](cplx (&W)[ICNT][3][3]) {                // [item][component][k]: inputs of the last inverse stage
+#pragma unroll
+        for (int i = 0; i < ICNT; ++i) {
+            const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+            if (t < HP * S3 && line_ok(p))
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) W[i][c][k] = buf[ix(c * HP + p, j + S3 * k)];
+        }
+    };
+    auto cross_first = [&](const cplx (&X)[3][3], const cplx (&Y)[3][3], int j, int p) {      // X x Y at the item's three points -> first forward stage
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+            cplx v[3];
+            for (int k = 0; k < 3; ++k)
+                v[k] = mk(X[c1][k].re * Y[c2][k].re - X[c2][k].re * Y[c1][k].re, X[c1][k].im * Y[c2][k].im - X[c2][k].im * Y[c1][k].im);
+            Butterfly<3, false>::run(v);
+            const int b = c * HP + p;
+            buf[ix(b, 3 * j)] = v[0];
+            buf[ix(b, 3 * j + 1)] = twmul<false>(v[1], tw[j]);
+            buf[ix(b, 3 * j + 2)] = twmul<false>(v[2], tw[2 * j]);
+        }
+    };
+    cplx old_sum[SCNT][2];
+    auto forward_and_store = [&](cplx* dst, const bool acc) {
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
+            if (acc) {
+#pragma unroll
+                for (int i = 0; i < SCNT; ++i) {
+                    const int t = tid + i * NT, p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
+                    if (t < NITEM && line_ok(p)) { const cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g); old_sum[i][0] = q[0]; old_sum[i][1] = q[1]; }
+                }
+            }
+        });
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SCNT; ++i) {
+            const int t = tid + i * NT;
+            if (t >= NITEM) break;
+            const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
+            if (!line_ok(p)) continue;
+            const cplx Zk = buf[ix(c * HP + p, kx)];
+            const cplx Zm = conj(buf[ix(c * HP + p, (kx == 0) ? 0 : L - kx)]);
+            cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g);
+            cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
+            if (acc) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
+            q[0] = v0;
+            q[1] = v1;
+        }
+    };
+
+    // ---- omega: spectrum -> grid, kept in registers -------------------------------------------------------------------------
+    cplx Wom[ICNT][3][3], Wy[ICNT][3][3];
+    stage_in(sp.inA);
+    read_win(Wom);
+#pragma unroll
+    for (int i = 0; i < ICNT; ++i) {                            // the velocity is requested before the barrier: in flight while the others read
+        const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+        if (t < HP * S3 && line_ok(p))
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) { const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g); Wy[i][c][k] = mk(q[0], q[1]); }
+    }
+    __syncthreads();
+    // ---- F1 = omega x U -> forward -> out A --------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < ICNT; ++i) {
+        const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+        if (t >= HP * S3 || !line_ok(p)) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Butterfly<3, true>::run(Wom[i][c]);
+        cross_first(Wom[i], Wy[i], j, p);
+    }
+    __syncthreads();
+    forward_and_store(sp.outA, false);
+    __syncthreads();
+    // ---- B_f: spectrum -> grid; F2' = omega x B_f -> forward -> running sum (out B) -----------------------------------------------
+    stage_in(sp.inB);
+    read_win(Wy);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ICNT; ++i) {
+        const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+        if (t >= HP * S3 || !line_ok(p)) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Butterfly<3, true>::run(Wy[i][c]);
+        cross_first(Wom[i], Wy[i], j, p);
+    }
+    __syncthreads();
+    forward_and_store(sp.outB, true);
+}
+
 // One tile per workgroup.  PAIRED = P > 1: the tile is narrower than a 128-byte line of the spectra (T = 8/P complex), so the P
 // tiles of a line are given to workgroups b, b+8, ..., which the dispatcher places on the same XCD at about the same time: the
 // rest of every line is then served by that XCD's L2 instead of being fetched from HBM again (speed only, never correctness).
@@ -537,10 +673,13 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 #ifndef SMO_X_ADJ_NT
 #define SMO_X_ADJ_NT 192
 #endif
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
+#ifndef SMO_X_SEQ_WAVES
+#define SMO_X_SEQ_WAVES SMO_X_WAVES
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? SMO_X_SEQ_WAVES : SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
-    __shared__ cplx buf[XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ)>::ELEMS];
+    __shared__ cplx buf[XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ || MODE == X_FUSED_ADJ_SEQ)>::ELEMS];
     // G > 192: half twiddle table — with the full one (6 KB at G = 384) the tile fits only three times into a CU's LDS instead of four
     constexpr bool HALF = (L > 192);
     constexpr int NTW = HALF ? L / 2 : L;
@@ -553,8 +692,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SMO_X_WAVES)
         const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);
         tile = (size_t)q * (8 * PAIRED) + PAIRED * (r % 8) + r / 8;
     }
-    if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
-    else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, tile * T, tid);
+    if constexpr (MODE == X_FUSED_ADJ_SEQ) {
+        if constexpr (HALF) x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
+        else x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, (const cplx*)tw_s, tile * T, tid);
+    } else {
+        if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
+        else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, tile * T, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -692,6 +836,7 @@ public:
         // natural stride 16*G*Gzl (a multiple of 64 KB at every supported size) they all fall on the same HBM channel: measured
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
+        { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_GRAPH"); if (e) graph_mode = atoi(e); }
         { const char* e = getenv("SMO_KD_GRAPH_MAXG"); if (e) graph_max_g = atoi(e); }
         { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
@@ -865,7 +1010,12 @@ public:
                 case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                default: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                default:
+                    // adjoint: the field groups one after the other through the tile buffer (tiles as wide as the forward pass's), unless
+                    // SMO_KD_ADJ_SEQ=0 asks for both at once in half-width tiles (round 1's kernel, kept for comparison)
+                    if (adj_seq) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    break;
             }
             return SMO_OK;
         });
@@ -906,6 +1056,7 @@ public:
     int zs_ready_fwd = -1, zs_ready_adj = -1;
     bool adj_cont = false;
     bool fuse_next = true;                     // SMO_KD_FUSE_NEXT=0: separate kernels (ablation)
+    bool adj_seq = true;                       // SMO_KD_ADJ_SEQ=0: adjoint x pass with both field groups in the tile at once
     int fwd_A(int n) {
         if (zs_ready_fwd == n) { zs_ready_fwd = -1; return SMO_OK; }
         return z_inverse(ZI_PLAIN, snap(n), 0, 1);

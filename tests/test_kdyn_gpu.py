@@ -285,10 +285,11 @@ def test_y_side_stack_is_bit_identical(monkeypatch):
         assert a[0] == b[0] and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
 
 
-@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYPAD", "24")])
+@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYPAD", "24"), ("SMO_KD_ADJ_SEQ", "0")])
 @pytest.mark.parametrize("N", [32, 48])
 def test_layout_and_fusion_knobs_are_bit_identical(monkeypatch, knob, off, N):
-    """Two pure performance devices must not change a single bit: (i) the update kernels run the next step's inverse z pass on the tile
+    """Pure performance devices must not change a single bit (SMO_KD_ADJ_SEQ: the adjoint x pass with the field groups one after the
+    other — the default — against both at once in half-width tiles): (i) the update kernels run the next step's inverse z pass on the tile
     they have just updated, in place in the exchange buffer (SMO_KD_FUSE_NEXT=0: separate kernels); (ii) the Ty planes are padded by one
     128-byte line against HBM channel conflicts (SMO_KD_TYPAD: other paddings / none).  Both adjoint types, with and without the
     grid-side stack (without it the adjoint sends two field groups and the fused pass must step aside)."""
@@ -316,7 +317,7 @@ def test_layout_and_fusion_knobs_are_bit_identical(monkeypatch, knob, off, N):
             assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]), (stack, adj)
 
 
-@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYSTACK", "0")])
+@pytest.mark.parametrize("knob,off", [("SMO_KD_FUSE_NEXT", "0"), ("SMO_KD_TYPAD", "0"), ("SMO_KD_TYSTACK", "0"), ("SMO_KD_ADJ_SEQ", "0")])
 def test_layout_and_fusion_knobs_are_bit_identical_at_G384(monkeypatch, knob, off):
     """The same pure-performance devices at the north-star grid (N = 256: half tiles, half twiddle table, XCD-paired x tiles): fused next z
     pass, Ty plane padding, grid-side stack.  Noise inputs (full spectrum, non-solenoidal: every branch of the per-mode update)."""
@@ -339,7 +340,12 @@ def test_layout_and_fusion_knobs_are_bit_identical_at_G384(monkeypatch, knob, of
         dom.drop_contexts()
     a, b = res
     assert a[0] == b[0] and np.array_equal(a[2], b[2])
-    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+    if knob == "SMO_KD_ADJ_SEQ":
+        # two different kernels for the same arithmetic: the compiler is free to contract a*b+c differently in each instantiation, so
+        # equality holds to rounding only (it is exact at the sizes of the test above)
+        assert rel(a[1][0], b[1][0]) < 1e-13 and rel(a[1][1], b[1][1]) < 1e-13
+    else:
+        assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
 
 
 @pytest.mark.parametrize("cost", ["Final", "Integrated"])

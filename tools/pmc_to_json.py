@@ -9,7 +9,8 @@ import re
 import sys
 from collections import defaultdict
 
-XMODE = {0: "kd_misc(x to grid)", 1: "kd_misc(x from grid)", 2: "kd_x_pass<fused_fwd>", 3: "kd_x_pass<fused_adj>"}
+XMODE = {0: "kd_misc(x to grid)", 1: "kd_misc(x from grid)", 2: "kd_x_pass<fused_fwd>", 3: "kd_x_pass<fused_adj>",
+         4: "kd_x_pass<fused_adj>"}      # 4 = X_FUSED_ADJ_SEQ: the field groups one after the other (the default adjoint pass since round 2)
 ZI = {0: "kd_z_inverse", 1: "kd_z_inverse<curl>", 2: "kd_misc(z inverse scaled)"}
 ZF = {0: "kd_misc(z forward plain)", 1: "kd_z_forward<fwd_update>", 2: "kd_z_forward<adj_update>", 3: "kd_misc(z forward nu)"}
 
