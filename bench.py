@@ -578,10 +578,14 @@ def main():
             try:
                 torch.cuda.empty_cache()
                 b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": 1, "warmup": 0, "no_cpu_baseline": True, "no_host_vectors": True})
-                st, _, e2, _, _, cf, _ = bench_kdyn(b, torch, rank, world)
+                st, _, e2, _, rf, cf, _ = bench_kdyn(b, torch, rank, world)
                 cfg["config_256"] = {"workload": cf["workload"] + " on 1 GPU", "ms_per_gradient": 1e3 * e2 / st, "gradient_evals_per_s": st / e2,
                                      "steps": st, "warmup": 0, "J": cf["J"], "stack_GB_per_gpu": cf["stack_GB"],
-                                     "checkpoint_interval": cf["checkpoint_interval"]}
+                                     "checkpoint_interval": cf["checkpoint_interval"],
+                                     # the same roofline accounting as the main line, for the dominant kernel of the G = 384 instantiations
+                                     "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                                          "avg_launch_ms", "bytes_per_launch", "achieved_algorithmic",
+                                                                          "whole_gradient_GBps", "whole_gradient_frac")}}
             except Exception as e:                   # never lose the main line because of the extra
                 cfg["config_256"] = {"error": repr(e)}
     if world > 1:
