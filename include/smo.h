@@ -147,6 +147,8 @@ int smo_snapshot_read(smo_ctx* ctx, int b, int index, double* out);
  *   SHB23 (FWD_Solve_SHB23.py:36-67): npts doubles either way.
  *   POIS  (FWD_Solve_Poiseuille.py:44-89): grid = float64[Nx][Nz] of a REAL field, coefficients = complex128[a][Nz] for the
  *          non-negative x wavenumbers n = 0..a-1, a = Nx/2 (the other half of the reference's complex spectrum is the Hermitian mirror). */
+/*   KDYN  (the transforms Dedalus performs for field['c'] / field['g'], FWD_Solve_KDyn.py:139-171, 635-637): which = 0: three grid fields
+ *          float64[3][G][G][G] -> truncated coefficients complex128[3][a][m][m]; which = 1: the inverse (zero padding, c2r ignores Im of kx = 0). */
 int smo_transform(smo_ctx* ctx, int which, const double* in, double* out);
 
 /* ---- slab-decomposed 3-D case: one process per GPU ---------------------------------

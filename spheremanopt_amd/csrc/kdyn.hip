@@ -1419,6 +1419,28 @@ public:
         return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 
+    // smo_transform for the 3-D case (host buffers): which = 0: three grid fields float64[3][G][G][G] -> their truncated coefficients
+    // complex128[3][a][m][m] (Dedalus' amplitude normalisation); which = 1: the inverse.  The same passes the solves use; single GPU.
+    double* d_tgrid = nullptr;
+    int transform_host(int which, const double* in, double* out) override {
+        if (cfg.world != 1 || K != 1) { set_error("smo_transform (KDYN): single-GPU contexts only"); return SMO_ERR_UNSUPPORTED; }
+        if (which != 0 && which != 1) { set_error("smo_transform (KDYN): which = 0 (grid -> coefficients) or 1 (coefficients -> grid)"); return SMO_ERR_ARG; }
+        if (!d_tgrid) SMO_TRY(pool.alloc(&d_tgrid, n_grid));
+        have_forward = false;                               // d_G (the adjoint's state) is the scratch spectrum here
+        if (which == 0) {
+            SMO_HIP(hipMemcpyAsync(d_tgrid, in, n_grid * sizeof(double), hipMemcpyHostToDevice, stream));
+            SMO_TRY(grid_to_coeff(d_tgrid, d_G));
+            SMO_HIP(hipMemcpyAsync(out, d_G, 3 * nmode * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+        } else {
+            SMO_HIP(hipMemcpyAsync(d_G, in, 3 * nmode * sizeof(cplx), hipMemcpyHostToDevice, stream));
+            SMO_TRY(coeff_to_grid(d_G, false, d_tgrid));
+            SMO_HIP(hipMemcpyAsync(out, d_tgrid, n_grid * sizeof(double), hipMemcpyDeviceToHost, stream));
+        }
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(stream));
+        return SMO_OK;
+    }
+
     int snapshot_read(int, int index, double* out) override {
         SMO_TRY(ensure(index));
         SMO_HIP(hipMemcpyAsync(out, snap(index), 3 * nmode * sizeof(cplx), hipMemcpyDeviceToHost, stream));

@@ -58,6 +58,9 @@ class KDynDomain:
         for c in self._ctx.values():
             c.close()
         self._ctx = {}
+        if getattr(self, "_transform_ctx", None) is not None:
+            self._transform_ctx.close()
+            self._transform_ctx = None
 
     def any_context(self):
         if not self._ctx:
@@ -95,6 +98,15 @@ def _coeff_to_grid_host(dom, C):
     return np.fft.irfft(p, n=G, axis=0) * float(G) ** 3
 
 
+def _coeff3_to_grid(dom, C3):
+    """(3,a,m,m) coefficients -> (3,G,G,G) grid values with the DEVICE transform (smo_transform, which = 1: the passes the solves use)."""
+    ctx = getattr(dom, "_transform_ctx", None)             # a context of its own: smo_transform uses the adjoint state as scratch
+    if ctx is None:
+        ctx = dom._transform_ctx = _capi.Context(_capi.SMO_KDYN, dom.Npts, dom.interval, 1e-3, 1, 1., device=dom.device)
+    C3 = np.ascontiguousarray(C3, dtype=np.complex128)
+    return ctx.transform(1, C3.view(np.float64).reshape(-1), out_len=3 * dom.G ** 3).reshape(3, dom.G, dom.G, dom.G)
+
+
 def _curl_noise(dom, seed, frac=0.25):
     """The reference's random solenoidal field (FWD_Solve_KDyn.py:220-243): phi = filtered noise, field = grad(phi) x (1,1,1).
     ``filter_field`` masks by INDEX fraction (> frac zeroed) on the (a, m, m) coefficient array, which removes every negative
@@ -109,7 +121,7 @@ def _curl_noise(dom, seed, frac=0.25):
     kc = np.concatenate([np.arange(0, kmax + 1), np.arange(-kmax, 0)]).astype(float)
     kx, ky, kz = np.meshgrid(np.arange(a, dtype=float), kc, kc, indexing='ij')
     comps = [1j * (ky - kz) * c, 1j * (kz - kx) * c, 1j * (kx - ky) * c]
-    return np.stack([_coeff_to_grid_host(dom, h) for h in comps])
+    return _coeff3_to_grid(dom, np.stack(comps))
 
 
 def FWD_Solve_IVP_Prep(Bx0, Ux0, domain, Rm, dt, N_ITERS):
@@ -118,7 +130,7 @@ def FWD_Solve_IVP_Prep(Bx0, Ux0, domain, Rm, dt, N_ITERS):
     ctx.forward([Bx0, Ux0])
     C = ctx.snapshot(N_ITERS + 1).view(np.complex128).reshape(3, domain.a, domain.m, domain.m)
     ctx.close()
-    return [_coeff_to_grid_host(domain, C[i]) for i in range(3)]
+    return list(_coeff3_to_grid(domain, C))
 
 
 def _analytic_flow(dom):

@@ -397,3 +397,21 @@ def test_hip_graph_is_off_where_it_does_not_apply(monkeypatch):
     assert ctx.get(2) == 0
     ctx.timing_enable(True)
     small.drop_contexts()
+
+
+@pytest.mark.parametrize("N", [16, 40])
+def test_device_transform_pair(N):
+    """smo_transform for the 3-D case: coefficients -> grid equals the host NumPy transform the IC generator used before, and
+    grid -> coefficients inverts it (band-limited input)."""
+    dom = kdyn.KDynDomain(N)
+    rs = np.random.RandomState(3)
+    C = rs.standard_normal((3, dom.a, dom.m, dom.m)) + 1j * rs.standard_normal((3, dom.a, dom.m, dom.m))
+    C[:, 0] = 0.5 * (C[:, 0] + np.conj(C[:, 0][:, ::-1, ::-1].take(np.r_[-1, :dom.m - 1], axis=1).take(np.r_[-1, :dom.m - 1], axis=2)))   # Hermitian kx = 0 plane
+    g_dev = kdyn._coeff3_to_grid(dom, C)
+    g_host = np.stack([kdyn._coeff_to_grid_host(dom, C[i]) for i in range(3)])
+    assert rel(g_dev, g_host) < 1e-13
+    ctx = dom._transform_ctx
+    back = ctx.transform(0, g_dev.reshape(-1), out_len=2 * 3 * dom.a * dom.m * dom.m).view(np.complex128).reshape(C.shape)
+    o = _oracle(N, 1., 1e-3, 1, "Final")
+    assert rel(back, np.stack([o.to_coeff(g_host[i]) for i in range(3)])) < 1e-13
+    dom.drop_contexts()
