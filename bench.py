@@ -276,6 +276,11 @@ def _slab_run(torch, N, Rm, dt, n_iters, steps, warm, ckpt=1):
         raise RuntimeError("slab solver construction failed: %r" % (last_err,))
     Bl = s.local_slab(kdyn.synthetic_field(G, 1)); Ul = s.local_slab(kdyn.synthetic_field(G, 2))
     out = [torch.empty_like(Bl), torch.empty_like(Ul)]
+    # how many pipelined chunks hide the transposes best depends on the node's xGMI rate: try the candidates once (untimed region), unless
+    # SMO_SLAB_CHUNKS pins the choice
+    s.chunk_autotune = None
+    if hasattr(s, "autotune_chunks") and "SMO_SLAB_CHUNKS" not in os.environ and os.environ.get("SMO_BENCH_AUTOTUNE", "1") != "0":
+        s.chunk_autotune = {str(k): v for k, v in s.autotune_chunks([Bl, Ul]).items()}
     # warm-up passes time every kernel class (breakdown); the timed region records HIP events only around the dominant one, as on one GPU
     # (events around all ~8 launches of a step pair would cost about as much as a thin slab's kernel)
     s.ctx.timing_enable(True)
@@ -342,7 +347,7 @@ def bench_kdyn_slab(a, torch, rank, world):
                           "%d field-group exchanges per step pair, %d pipelined z chunks)"
                           % (world, {"rccl": "RCCL grouped send/recv", "callback": "callback (host-staged, test only)"}.get(s.transport, s.transport),
                              s.exchanges_per_step_pair, s.K),
-           "transport": s.transport,
+           "transport": s.transport, "chunk_autotune_s": getattr(s, "chunk_autotune", None),
            "exchange_MB_sent_per_gpu_per_step_pair": s.exchanges_per_step_pair * _slab_elems(N, world) * 16 / 1e6 * (world - 1) / world,
            "grid_states_kept_GB_per_gpu": s.ctx.get(1) / 1e9}
     # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)
@@ -357,6 +362,7 @@ def bench_kdyn_slab(a, torch, rank, world):
             cfg["config_256"] = {"workload": "Kinematic dynamo 3D Fourier %d^3 slab-decomposed across %d GPUs, T=%g, dt=%g" % (big, world, dt * n_iters, dt),
                                  "ms_per_gradient": 1e3 * el2, "gradient_evals_per_s": 1.0 / el2, "steps": 1, "warmup": 0, "J": J2,
                                  "stack_GB_per_gpu": s2.ctx.stack_bytes / 1e9, "checkpoint_interval": int(s2.ctx.get(0)),
+                                 "chunks": s2.K, "chunk_autotune_s": getattr(s2, "chunk_autotune", None),
                                  "exchange_MB_sent_per_gpu_per_step_pair": s2.exchanges_per_step_pair * _slab_elems(big, world) * 16 / 1e6 * (world - 1) / world}
             del s2
         except Exception as e:                       # never lose the main line because of the extra

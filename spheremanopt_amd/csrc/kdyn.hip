@@ -1212,6 +1212,14 @@ public:
     // Called once the transport exists (collective): the ranks agree on what each of them decided from its own free HBM — the
     // checkpoint interval and whether the grid-side states are kept (that fixes how many field groups an adjoint step sends) —
     // before the first exchange could mismatch, and the chunk pipeline is set up.
+    // stream and events of the chunk pipeline, for the current K
+    int pipeline_resources() {
+        if (!cstream) SMO_HIP(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        if (!ev_main) SMO_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+        for (auto* vec : {&ev_in, &ev_ph, &ev_out})
+            while ((int)vec->size() < K) { hipEvent_t e; SMO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); vec->push_back(e); }
+        return SMO_OK;
+    }
     int comm_attach() {
         double v[3] = {d_tystack ? 1.0 : 0.0, (double)ck, (double)ck * ck};
         SMO_TRY(allreduce(v, 3));
@@ -1233,10 +1241,7 @@ public:
         if (k <= 0) k = cfg.world > 1 ? std::max(1, std::min(4, (int)(((size_t)g.G * g.Gzr) / 9216))) : 1;
         while (k > 1 && (g.Gzr % k || (g.Gzr / k) % 2 || ((size_t)g.G * (g.Gzr / k)) % 4)) --k;
         if (k != K) SMO_TRY(set_chunks(k));
-        if (!cstream) SMO_HIP(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
-        if (!ev_main) SMO_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
-        for (auto* vec : {&ev_in, &ev_ph, &ev_out})
-            while ((int)vec->size() < K) { hipEvent_t e; SMO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); vec->push_back(e); }
+        SMO_TRY(pipeline_resources());
         have_forward = false;
         return SMO_OK;
     }
@@ -1450,7 +1455,12 @@ public:
 
     // ---- phase-level entry for the slab-decomposed driver (smo_kdyn_op) -------------------------------------------------
     int kdyn_op(int op, int i0, int i1, void* p0, void* p1, double* out) override {
-        if (op == SMO_KD_SET_CHUNKS) return set_chunks(i0);
+        if (op == SMO_KD_SET_CHUNKS) {                       // also on a context that runs the loop itself: re-tune the exchange pipeline
+            SMO_HIP(hipStreamSynchronize(stream));
+            if (cstream) SMO_HIP(hipStreamSynchronize(cstream));
+            SMO_TRY(set_chunks(i0));
+            return comm.ready() ? pipeline_resources() : SMO_OK;
+        }
         if (op == SMO_KD_SET_BUFFERS) {
             if (!p0 || !p1) { set_error("SMO_KD_SET_BUFFERS: null buffer"); return SMO_ERR_ARG; }
             zs = static_cast<cplx*>(p0); ys = static_cast<cplx*>(p1); zs_ready_fwd = zs_ready_adj = -1;

@@ -410,6 +410,41 @@ class LibSlabKDyn:
         for i in range(n):
             vals[i] = float(t[i])
 
+    def set_chunks(self, K):
+        """Collective: cut the local z slab into K pipelined chunks (smo_kdyn_op SMO_KD_SET_CHUNKS); raises if K does not divide it."""
+        import ctypes as C
+        _capi._check(_capi.lib().smo_kdyn_op(self.ctx._h, SET_CHUNKS, int(K), 0, C.c_void_p(None), C.c_void_p(None), None))
+        self.K = int(self.ctx.comm_get(0))
+
+    def autotune_chunks(self, X, candidates=(1, 2, 4)):
+        """Collective: time one forward + adjoint solve per candidate chunk count and keep the fastest (slowest rank decides, so every
+        rank picks the same).  How well the transposes hide behind the grid-side kernels depends on the xGMI rate of the node, which no
+        single-GPU measurement can tell; a few solves at start-up can.  Returns {K: seconds}."""
+        import time
+        torch, times = self.torch, {}
+        out = [torch.empty(self.vec_len, dtype=torch.float64, device=self.dev) for _ in range(2)]
+        for K in candidates:
+            try:
+                self.set_chunks(K)
+            except _capi.SmoError:
+                continue                                   # K does not divide the slab into even parts
+            if self.K != K:
+                continue
+            self.forward(X); self.adjoint("Discrete", out)  # first run with this K: allocations, communicator warm-up
+            torch.cuda.synchronize(self.dev)
+            if self.world > 1:
+                _dist().barrier()
+            t0 = time.perf_counter()
+            self.forward(X); self.adjoint("Discrete", out)
+            torch.cuda.synchronize(self.dev)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if self.host_staged else self.dev)
+            if self.world > 1:
+                _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
+            times[K] = float(t.item())
+        if times:
+            self.set_chunks(min(times, key=times.get))
+        return times
+
     def _sync_inputs(self):
         self.torch.cuda.current_stream(self.dev).synchronize()     # inputs produced by torch kernels; libsmo runs on its own streams
 

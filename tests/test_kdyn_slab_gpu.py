@@ -301,3 +301,39 @@ def test_communicator_errors():
     with pytest.raises(_capi.SmoError) as e:
         ctx.forward([x, x])
     assert "transport failed" in str(e.value) and isinstance(ctx._transport_error, RuntimeError)
+
+
+def _autotune_worker(rank, world, port, N, n, out):
+    sys.path.insert(0, ROOT)
+    os.environ.pop("SMO_SLAB_CHUNKS", None)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from spheremanopt_amd import kdyn
+        from spheremanopt_amd.kdyn_slab import LibSlabKDyn
+        G = 3 * N // 2
+        B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+        s = LibSlabKDyn(N, 1., 1e-3, n, "Integrated")
+        X = [s.local_slab(B), s.local_slab(U)]
+        J0 = s.forward(X); g0 = [t.clone() for t in s.adjoint("Discrete")]
+        times = s.autotune_chunks(X, candidates=(1, 2, 3, 4, 5))
+        J1 = s.forward(X); g1 = s.adjoint("Discrete")
+        if rank == 0:
+            np.savez(out, J0=J0, J1=J1, K=s.K, tried=np.array(sorted(times)), best=min(times, key=times.get),
+                     e=max(float((g1[i] - g0[i]).abs().max()) for i in range(2)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunk_autotune_keeps_results(tmp_path):
+    """Re-chunking a live in-library context (SMO_KD_SET_CHUNKS) and the start-up autotune of the exchange pipeline: the candidates that
+    divide the slab are tried, the fastest is kept on every rank, and the numbers do not depend on the choice."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_autotune_worker, args=(2, _free_port(), 32, 4, out), nprocs=2, join=True)        # 24 local planes: 1, 2, 3, 4 give even chunks; 5 does not
+    r = np.load(out)
+    assert list(r["tried"]) == [1, 2, 3, 4] and int(r["K"]) == int(r["best"])
+    assert abs(float(r["J1"]) - float(r["J0"])) <= 1e-13 * abs(float(r["J0"])) and float(r["e"]) < 1e-13
