@@ -59,7 +59,7 @@ def test_in_library_loop_over_rccl_between_gpus(tmp_path, N, cost, adj, ckpt, ch
     import torch.multiprocessing as mp
     from oracle.kdyn import KDynOracle
     world = 2
-    for w in (8, 4):
+    for w in (4,):                                          # at most 4 ranks + this process on the node
         if _ngpu() >= w and (N // 2) % w == 0 and (3 * N // 2) % w == 0:
             world = w
             break
