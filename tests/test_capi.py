@@ -91,3 +91,19 @@ def test_header_is_plain_c_and_matches_the_ctypes_struct(tmp_path):
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for f in fields:
         assert '("%s"' % f in doc, f
+
+
+def _build_c_smoke(tmpdir):
+    """gcc -std=c99 -Wall -Wextra -Werror: include/smo.h must be valid C, and a plain C program must link against libsmo.so."""
+    import subprocess
+    exe = os.path.join(str(tmpdir), "abi_smoke")
+    libdir = os.path.join(ROOT, "spheremanopt_amd", "lib")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+           "-o", exe, "-L" + libdir, "-lsmo", "-lm", "-Wl,-rpath," + libdir]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return exe
+
+
+def test_header_is_valid_c_and_a_c_program_links(tmp_path):
+    assert os.path.exists(_build_c_smoke(tmp_path))

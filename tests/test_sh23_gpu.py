@@ -144,3 +144,22 @@ def test_reference_ic_recipe_with_device_prep():
     ref = o.to_grid(o.stack[:, 101])
     ref *= np.sqrt(0.0725 / np.mean(ref * ref))
     assert rel(X, ref) < 1e-9
+
+
+def test_c_program_through_the_c_abi(tmp_path):
+    """tests/c/abi_smoke.c — plain C against include/smo.h — runs one gradient, the device-vector calls and the error path; its numbers
+    must be the Python binding's, bit for bit (same library, same inputs)."""
+    import subprocess
+    from test_capi import _build_c_smoke
+    exe = _build_c_smoke(tmp_path)
+    N, n = 64, 40
+    p = subprocess.run([exe, str(N), str(n)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    got = dict(ln.split() for ln in p.stdout.splitlines())
+    i = np.arange(2 * N)
+    x = 0.3 * np.sin(2.0 * np.pi * 3.0 * i / (2 * N)) + 0.1 * np.cos(2.0 * np.pi * 5.0 * i / (2 * N))
+    ctx = _capi.Context(_capi.SMO_SH23, N, (0., 12. * np.pi), 0.1, n, -0.3)
+    J = ctx.forward([x]); g = ctx.adjoint(None)[0]
+    assert float(got["J"]) == J or abs(float(got["J"]) - J) <= 1e-14 * abs(J)          # libm sin/cos of the C program vs NumPy's
+    assert abs(float(got["inner"]) - ctx.inner(x, g)) <= 1e-12 * abs(ctx.inner(x, g)) and got["inner"] == got["inner_dev"]
+    assert abs(float(got["combo_norm2"]) - float(np.sum((2 * x - g) ** 2))) <= 1e-12 * float(np.sum((2 * x - g) ** 2))
