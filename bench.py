@@ -519,6 +519,20 @@ def main():
         torch.distributed.init_process_group(backend, timeout=datetime.timedelta(minutes=int(os.environ.get("SMO_BENCH_PG_TIMEOUT_MIN", "15"))))
     wl = a.workload or "kdyn"
     scaling = "weak"
+    watchdog = None
+    if world > 1:
+        # A collective that never completes (a rank lost inside an RCCL call, a fabric problem) must end this job with an error, not sit
+        # on the node until an outer limit kills it: torch's process-group timeout covers torch's collectives, this timer covers the rest.
+        import threading
+        limit = 60.0 * float(os.environ.get("SMO_BENCH_WATCHDOG_MIN", "25"))
+
+        def _give_up():
+            sys.stderr.write("rank %d: bench.py watchdog: no result after %.0f minutes, giving up\n" % (rank, limit / 60.0))
+            sys.stderr.flush()
+            os._exit(124)
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if wl == "sh23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
     elif wl == "shb23":
@@ -610,6 +624,8 @@ def main():
         if secondary:
             out["secondary"] = secondary
         print(json.dumps(out))
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         torch.distributed.destroy_process_group()
 
