@@ -798,7 +798,19 @@ public:
         if (idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
         const int w = idx / ck, last = std::min(cfg.n_iters, w * ck + ck - 1);
         scratch_window = w;
-        for (int n = w * ck; n < last; ++n) SMO_TRY(step_fwd(n, false));
+        // the forward steps that rebuild the window pass through the grid-side form Ty(B^_n) of the states they start from: keep it
+        // (one slot per step of the window), so that the adjoint steps of those states neither transform their snapshot again nor
+        // send it — for ck = 2 that is every second adjoint step: two kernels and one exchanged field group less
+        tycache_window = d_tycache ? w : -1;
+        tycache_count = last - w * ck;
+        for (int n = w * ck; n < last; ++n) SMO_TRY(step_fwd(n, d_tycache != nullptr));
+        if (d_tycache && last < cfg.n_iters) {
+            // ... and of the last state of the window: its inverse z pass is already in the exchange buffer (left by the update that
+            // produced it), one y pass puts it beside the others — every adjoint step of the window then runs with one field group
+            tycache_count += 1;
+            SMO_TRY(fwd_A(last));
+            for (int k = 0; k < K; ++k) { SMO_TRY(exchange(true, 1, k, stream)); SMO_TRY(y_pass(true, 0, 1, tyslot(last, k), k)); }
+        }
         return SMO_OK;
     }
     Geom geom(int nfields, int k = 0) const { Geom q = g; q.blk = (size_t)nfields * tzc; q.cblk = (size_t)cfg.world * 2 * tzc; q.zg0 = k * g.Gzl; return q; }
@@ -873,6 +885,14 @@ public:
                 SMO_TRY(pool.alloc(&d_tystack, (size_t)cfg.n_iters * fld));
                 stack_bytes += need;
             }
+        }
+        if (ck > 1) {                                        // Ty cache of the window being replayed (SMO_KD_TYCACHE=0 disables)
+            const char* env = getenv("SMO_KD_TYCACHE");
+            size_t free_b = 0, total_b = 0;
+            SMO_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t need = (size_t)ck * fld * sizeof(cplx);
+            const size_t rest = (2 * n_ex + 3 * fld + 6 * nmode) * sizeof(cplx) + n_grid * 8 + ((size_t)6 << 30);
+            if (!(env && atoi(env) == 0) && need + rest < free_b) SMO_TRY(pool.alloc(&d_tycache, (size_t)ck * fld));
         }
         SMO_TRY(pool.alloc(&d_ty, 2 * fld));
         SMO_TRY(pool.alloc(&d_acc, fld));
@@ -1048,9 +1068,15 @@ public:
     // step then reads B_f from there: no z / y pass of the snapshot (2 of its 8 kernels) and, with slabs, one field group less to
     // exchange.
     cplx* d_tystack = nullptr;
-    cplx* tyslot(int n, int k = 0) { return d_tystack + (size_t)n * fld + (size_t)k * fldc; }
+    cplx* d_tycache = nullptr;                 // checkpoint windows: Ty(B^_n) of the window being replayed, [ck][fld]
+    int tycache_window = -1, tycache_count = 0;
+    bool in_tycache(int n) const { return d_tycache && tycache_window >= 0 && n >= tycache_window * ck && n < tycache_window * ck + tycache_count; }
+    cplx* tyslot(int n, int k = 0) {
+        if (d_tystack) return d_tystack + (size_t)n * fld + (size_t)k * fldc;
+        return d_tycache + (size_t)(n - tycache_window * ck) * fld + (size_t)k * fldc;
+    }
     cplx* tyw(int f, int k) { return d_ty + (size_t)f * fld + (size_t)k * fldc; }       // work copy of Ty: field group f, chunk k
-    bool have_ty(int n) const { return d_tystack != nullptr && n >= 0 && n < cfg.n_iters; }
+    bool have_ty(int n) const { return n >= 0 && n < cfg.n_iters && (d_tystack != nullptr || in_tycache(n)); }
     // zs_ready_*: the z-side buffer already holds the inverse z pass of snapshot n / of curl(G^) for adjoint index idx, left there by
     // the update kernel of the step before (NX_*); every other writer of the z-side buffer clears them.
     int zs_ready_fwd = -1, zs_ready_adj = -1;
@@ -1221,8 +1247,8 @@ public:
         return SMO_OK;
     }
     int comm_attach() {
-        double v[3] = {d_tystack ? 1.0 : 0.0, (double)ck, (double)ck * ck};
-        SMO_TRY(allreduce(v, 3));
+        double v[4] = {d_tystack ? 1.0 : 0.0, (double)ck, (double)ck * ck, d_tycache ? 1.0 : 0.0};
+        SMO_TRY(allreduce(v, 4));
         const double W = cfg.world;
         if (std::fabs(W * v[2] - v[1] * v[1]) > 0.5) {
             set_error("KDYN: the ranks chose different checkpoint intervals from their free HBM (mine: %d); pass an explicit smo_config.ckpt", ck);
@@ -1233,6 +1259,11 @@ public:
             SMO_TRY(pool.free_one(d_tystack));
             stack_bytes -= (size_t)cfg.n_iters * fld * sizeof(cplx);
             d_tystack = nullptr;
+        }
+        if (d_tycache && v[3] < W - 0.5) {                // the same for the Ty cache of the checkpoint windows
+            SMO_HIP(hipStreamSynchronize(stream));
+            SMO_TRY(pool.free_one(d_tycache));
+            d_tycache = nullptr; tycache_window = -1;
         }
         int k = 0;
         if (const char* e = getenv("SMO_SLAB_CHUNKS")) k = atoi(e);
@@ -1328,6 +1359,7 @@ public:
     // everything of a forward solve that is a kernel launch (the partial sums of J stay in d_part)
     int fwd_enqueue(const double* B, const double* U) {
         const int N = cfg.n_iters;
+        tycache_window = -1;                               // the states change: whatever the last adjoint sweep cached is stale
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         // U: truncate to the retained modes, back to the grid (NCC fields are band-limited by the solver)
         SMO_TRY(grid_to_coeff(U, d_G));
