@@ -282,6 +282,31 @@ class Context:
         _check(lib().smo_inner_dev(self._h, _dev_ptr(x), _dev_ptr(y), out.ctypes.data_as(C.POINTER(C.c_double))))
         return float(out[0]) if self.batch == 1 else out
 
+    # -- either kind of vector: NumPy arrays (staged over PCIe) or devvec.DeviceVector (already in HBM) ---------------------------------
+    @staticmethod
+    def _on_device(v):
+        return hasattr(v, "ptr") and hasattr(v, "numpy")
+
+    def forward_any(self, X):
+        return self.forward_dev(X) if self._on_device(X[0]) else self.forward(X)
+
+    def adjoint_any(self, X, adjoint_type="Discrete"):
+        """Device vectors in -> fresh device vectors out (like the reference's fresh arrays); anything else: NumPy arrays out."""
+        if X is not None and len(X) and self._on_device(X[0]):
+            from .devvec import DeviceVector
+            grads = [DeviceVector(self.vec_len * self.batch, self.cfg.device) for _ in range(self.ncomp)]
+            self.adjoint_dev(list(X), grads, adjoint_type)
+            return grads
+        return self.adjoint(None, adjoint_type)
+
+    def inner_any(self, x, y):
+        dx, dy = self._on_device(x), self._on_device(y)
+        if dx and dy:
+            return self.inner_dev(x, y)
+        if dx or dy:
+            raise TypeError("inner product: one operand is a DeviceVector and the other is not")
+        return self.inner(x, y)
+
     # -- slab communicator (KDYN, world > 1): the transposes then happen inside smo_forward / smo_adjoint ----------------
     def comm_init(self, unique_id):
         """Collective: RCCL communicator over the context's `world` ranks from the 128 bytes of comm_unique_id()."""

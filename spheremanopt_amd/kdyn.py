@@ -213,11 +213,7 @@ def ADJ_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     """[dJ/dB0, dJ/dU] as flat grid vectors; valid right after FWD_Solve_IVP_Lin at the same X0."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(Rm, dt, N_ITERS, Cost_function)
-    if isinstance(X0[0], DeviceVector):                     # device vectors in, device vectors out (fresh ones, like the reference's arrays)
-        grads = [DeviceVector(ctx.vec_len, domain.device) for _ in range(2)]
-        ctx.adjoint_dev([X0[0], X0[1]], grads, Adjoint_type)
-        return grads
-    return ctx.adjoint(None, Adjoint_type)
+    return ctx.adjoint_any([X0[0], X0[1]], Adjoint_type)     # device vectors in, device vectors out (fresh ones, like the reference's arrays)
 
 
 def File_Manips(k):
@@ -228,9 +224,5 @@ def File_Manips(k):
 
 def Inner_Prod_3(x, y, domain, random_arg=None):
     """Sum over the three components of the grid mean of x*y."""
-    if isinstance(x, DeviceVector) and isinstance(y, DeviceVector):
-        return domain.any_context().inner_dev(x, y)
-    if isinstance(x, DeviceVector) or isinstance(y, DeviceVector):
-        raise TypeError("Inner_Prod_3: one operand is a DeviceVector and the other is not")
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)
 

@@ -104,7 +104,7 @@ def FWD_Solve_Discrete(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt
     """Objective: -1/2 dt sum_n <U_n,U_n>  (s = 0: time-averaged kinetic energy)  or  1/2 <grad psi, grad psi>, lap psi = rho(T)  (s = 1:
     mix-norm).  Fills the device snapshot stack."""
     ctx = domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ)
-    J = ctx.forward([_vec(U0)])
+    J = ctx.forward_any([_vec(U0)])
     for k in ('u_fwd', 'w_fwd', 'b_fwd'):
         X_FWD_DICT[k].ctx = ctx
     if getattr(domain, "write_products", False):           # scalar_data_s1 / CheckPoints_s1 like the reference (:945-1151)
@@ -121,12 +121,12 @@ def File_Manips(k):
 
 def ADJ_Solve_Discrete(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-04, s=0, Prandtl=1., δ=0.25, Sim_Type="Non_Linear"):
     """[dJ/dU0] with respect to Inner_Prod_Discrete; valid right after FWD_Solve_Discrete at the same U0 (it replays that stack)."""
-    return domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ).adjoint(None, "Discrete")
+    return domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ).adjoint_any([_vec(U0)], "Discrete")
 
 
 def Inner_Prod_Discrete(x, y, domain, W=None):
     """(1/V) sum W (x_u y_u + x_w y_w) with the first-order Gauss-grid weights of weightMatrixDisc (:91-118)."""
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)
 
 
 def weightMatrixDisc(domain):
@@ -204,7 +204,7 @@ def FWD_Solve_Cnts(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-
     of rho(T) (s = 1), integrals exact for the truncated series.  Snapshots: coefficients of u, w, b before every step."""
     _need_cnts(domain)
     ctx = domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ)
-    J = ctx.forward([_vec(U0)])
+    J = ctx.forward_any([_vec(U0)])
     for k in ('u_fwd', 'w_fwd', 'b_fwd'):
         X_FWD_DICT[k].ctx = ctx
     return J
@@ -213,13 +213,13 @@ def FWD_Solve_Cnts(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-
 def ADJ_Solve_Cnts(U0, domain, Reynolds, Richardson, N_ITERS, X_FWD_DICT, dt=1e-04, s=0, Prandtl=1., δ=0.25, Sim_Type="Non_Linear"):
     """[u_adj, w_adj] after N_ITERS steps of the script's adjoint IVP on the 3/2 grid: an O(dt)-consistent approximation of dJ/dU0."""
     _need_cnts(domain)
-    return domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ).adjoint(None, "Continuous")
+    return domain.context(Reynolds, Richardson, N_ITERS, dt, s, Prandtl, δ).adjoint_any([_vec(U0)], "Continuous")
 
 
 def Inner_Prod_Cnts(x, y, domain, rand_arg=None):
     """(1/V) integ (x_u y_u + x_w y_w): grid product, truncated to the modes, integrated exactly (Integrate_Field :241-262)."""
     _need_cnts(domain)
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)
 
 
 Adjoint_type = "Discrete"

@@ -135,7 +135,7 @@ def FWD_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filenam
     """-J(X) with J = dt * sum_{n=0}^{N} (1/L) int u_n^2 dx; fills the device snapshot stack."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(dt, N_ITERS)
-    J = ctx.forward([X_k[0]])
+    J = ctx.forward_any([X_k[0]])                          # NumPy vector or devvec.DeviceVector
     X_FWD_DICT['A_fwd'].ctx = ctx
     if getattr(domain, "write_products", False):           # scalar_data/ and CheckPoints/ like the reference's file handlers
         from . import products
@@ -153,9 +153,9 @@ def ADJ_Solve_IVP_Lin(X_k, domain, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, filenam
     """[dJ/dX] on the scale-2 grid; valid right after FWD_Solve_IVP_Lin at the same X_k (it replays that stack)."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(dt, N_ITERS)
-    return ctx.adjoint(None, Adjoint_type)
+    return ctx.adjoint_any([X_k[0]], Adjoint_type)
 
 
 def Inner_Prod(x, y, domain, rand_arg=None):
     """(1/L) int x y dx = mean over the scale-2 grid."""
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)

@@ -129,7 +129,7 @@ def Generate_IC(Npts, Z=(-20., 20.), M_0=1.0, seed=42, dt=1e-2, prep_steps=100, 
 def FWD_Solve_IVP_Discrete(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=None):
     """-J(X), J = dt * sum_{n=0}^{N} <u_n,u_n>_W ; fills the device snapshot stack with the grid states."""
     ctx = domain.context(dt, N_ITERS)
-    J = ctx.forward([X_k[0]])
+    J = ctx.forward_any([X_k[0]])
     X_FWD_DICT['A_fwd'].ctx = ctx
     if getattr(domain, "write_products", False) and domain.dealias == 1:      # scalar_data_s1 / CheckPoints_s1 like the reference (:604-672)
         from . import products
@@ -145,12 +145,12 @@ def File_Manips(k):
 
 def ADJ_Solve_IVP_Discrete(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=None):
     """[dJ/dX]; valid right after FWD_Solve_IVP_Discrete at the same X_k."""
-    return domain.context(dt, N_ITERS).adjoint(None, "Discrete")
+    return domain.context(dt, N_ITERS).adjoint_any([X_k[0]], "Discrete")
 
 
 def Inner_Prod_Discrete(x, y, domain, Type_xy='np_vector'):
     """x . (W o y) / L_z with the reference's trapezoid-like weights."""
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)
 
 
 # ---- "Continuous" formulation (Dedalus IVP with dealias 2 in the reference; SHB:398-523, 685-794, 156-187) -------------------------
@@ -158,19 +158,19 @@ def Inner_Prod_Discrete(x, y, domain, Type_xy='np_vector'):
 def FWD_Solve_IVP_Cnts(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=None):
     """-J(X), J = dt * sum_n (1/Lz) integ(u_n^2); X on the scale-2 grid (2*Npts values); snapshots = T-coefficients."""
     ctx = domain.context(dt, N_ITERS)
-    J = ctx.forward([X_k[0]])
+    J = ctx.forward_any([X_k[0]])
     X_FWD_DICT['A_fwd'].ctx = ctx
     return J
 
 
 def ADJ_Solve_IVP_Cnts(X_k, domain, X_FWD_DICT, N_ITERS, dt=1e-02, filename=None):
     """[q(T)] of the continuous adjoint equation on the scale-2 grid (an O(dt)-consistent approximation of dJ/dX)."""
-    return domain.context(dt, N_ITERS).adjoint(None, "Continuous")
+    return domain.context(dt, N_ITERS).adjoint_any([X_k[0]], "Continuous")
 
 
 def Inner_Prod_Cnts(x, y, domain, Type_xy='np_vector'):
     """(1/Lz) integ(x*y): product on the scale-2 grid, truncated to Npts modes, integrated exactly."""
-    return domain.any_context().inner(x, y)
+    return domain.any_context().inner_any(x, y)
 
 
 def Generate_IC_Cnts(Npts, Z=(-20., 20.), M_0=1.0, seed=42, dt=1e-2, prep_steps=100, device=0):

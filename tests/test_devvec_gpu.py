@@ -133,3 +133,42 @@ def test_pinned_host_buffers_round_trip():
     with pytest.raises(ValueError):
         ctx.adjoint(None, out=[np.empty(3), np.empty(3)])
     dom.drop_contexts()
+
+
+def test_the_other_problems_accept_device_vectors():
+    """SH23, SHB23 (both formulations) and Poiseuille: the same callables with DeviceVectors — same numbers as with NumPy vectors, gradients
+    come back as DeviceVectors, and a short optimisation keeps its iterate sequence bit for bit."""
+    from spheremanopt_amd import poiseuille as pz, sh23, shb23
+    # SH23
+    dom, X = sh23.Generate_IC(0.0725, Npts=64, seed=42)
+    buf = sh23.GEN_BUFFER(dom, 30)
+    args = [dom, 0.1, 30, 30, buf, None, "Discrete"]
+    J = sh23.FWD_Solve_IVP_Lin([X], *args); g = sh23.ADJ_Solve_IVP_Lin([X], *args)[0]
+    Xd = DeviceVector.from_numpy(X)
+    Jd = sh23.FWD_Solve_IVP_Lin([Xd], *args); gd = sh23.ADJ_Solve_IVP_Lin([Xd], *args)[0]
+    assert Jd == J and isinstance(gd, DeviceVector) and np.array_equal(gd.numpy(), g)
+    assert sh23.Inner_Prod(Xd, gd, dom) == sh23.Inner_Prod(X, g, dom)
+    runs = []
+    for X0 in ([X], [DeviceVector.from_numpy(X)]):
+        R, F, Xo = Optimise_On_Multi_Sphere(X0, [0.0725], sh23.FWD_Solve_IVP_Lin, sh23.ADJ_Solve_IVP_Lin, sh23.Inner_Prod, args, (dom, None),
+                                            max_iters=3, alpha_k=1., LS='LS_wolfe', CG=True, verbose=False)
+        runs.append((R, F, to_host(Xo)[0]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and np.array_equal(runs[0][2], runs[1][2])
+    # SHB23, discrete formulation
+    dom, X = shb23.Generate_IC(128, M_0=0.0019, seed=42)
+    buf = shb23.GEN_BUFFER(128, dom, 20)
+    J = shb23.FWD_Solve_IVP_Discrete([X], dom, buf, 20, 1e-2); g = shb23.ADJ_Solve_IVP_Discrete([X], dom, buf, 20, 1e-2)[0]
+    Xd = DeviceVector.from_numpy(X)
+    Jd = shb23.FWD_Solve_IVP_Discrete([Xd], dom, buf, 20, 1e-2); gd = shb23.ADJ_Solve_IVP_Discrete([Xd], dom, buf, 20, 1e-2)[0]
+    assert Jd == J and np.array_equal(gd.numpy(), g) and shb23.Inner_Prod_Discrete(Xd, gd, dom) == shb23.Inner_Prod_Discrete(X, g, dom)
+    # Poiseuille, discrete formulation
+    from oracle.poiseuille import PoiseuilleOracle, synthetic_ic
+    X = synthetic_ic(PoiseuilleOracle(24, 24, dt=5e-3, N_ITERS=5, s=0, delta=0.3), 42)
+    dom = pz.PoiseuilleDomain(24, 24)
+    buf = pz.GEN_BUFFER(24, 24, dom, 5)
+    args = [dom, 500., 0.05, 5, buf, 5e-3, 0, 1., 0.3]
+    J = pz.FWD_Solve_Discrete([X], *args); g = pz.ADJ_Solve_Discrete([X], *args)[0]
+    Xd = DeviceVector.from_numpy(X)
+    Jd = pz.FWD_Solve_Discrete([Xd], *args); gd = pz.ADJ_Solve_Discrete([Xd], *args)[0]
+    assert Jd == J and np.array_equal(gd.numpy(), g) and pz.Inner_Prod_Discrete(Xd, gd, dom) == pz.Inner_Prod_Discrete(X, g, dom)
+    dom.drop_contexts()
