@@ -277,7 +277,6 @@ def test_bench_size_slabs_agree_with_the_single_gpu_path(tmp_path, N, world, chu
 def test_communicator_errors():
     """world > 1 without a communicator: the loop entry points refuse (the phase-level entry still works); a single-slab context has
     nothing to exchange; smo_comm_get reports the pipeline."""
-    import ctypes as C
     from spheremanopt_amd import _capi
     ctx = _capi.Context(_capi.SMO_KDYN, 16, (0., 2 * np.pi), 1e-3, 2, 1.0, rank=1, world=2)
     x = np.zeros(ctx.vec_len)

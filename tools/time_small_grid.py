@@ -6,7 +6,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np  # noqa: E402
+
 
 from spheremanopt_amd import kdyn  # noqa: E402
 from spheremanopt_amd.devvec import DeviceVector, to_device  # noqa: E402
