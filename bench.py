@@ -468,6 +468,15 @@ def bench_kdyn(a, torch, rank, world):
            "parallelism": "1 GPU" if world == 1 else "replicas only (x%d independent gradients)" % world}
     if host:
         cfg["value_host_vectors"] = host
+    # the timed gradient against the committed oracle value for exactly this workload (data under tests/golden/, not oracle code)
+    fx = os.path.join(ROOT, "tests", "golden", "oracle_kdyn_c4_%d_n%d.npz" % (N, n_iters))
+    if os.path.exists(fx):
+        try:
+            Jo = float(np.load(fx)["J_Final"])
+            cfg["J_oracle_fixture"] = Jo
+            cfg["J_matches_oracle_1e-6"] = bool(abs(J - Jo) <= 1e-6 * abs(Jo))
+        except Exception:
+            pass
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1)

@@ -137,6 +137,32 @@ def test_config4_fixture_with_windowed_checkpoints():
     _fixture_run("oracle_kdyn_c4_128_n50.npz", ckpt=7)
 
 
+def test_config4_full_length_fixture():
+    """BASELINE configs[3] at its full length — 128^3, 1000 steps, the very gradient `bench.py` times — against the oracle run committed as
+    tests/golden/oracle_kdyn_c4_128_n1000.npz (tools/gen_golden_kdyn_full.py: two hours of CPU, 55 GB of RAM): J of both cost functionals
+    and the discrete-adjoint gradients with respect to B0 and U."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c4_128_n1000.npz"))
+    N, n, dt, Rm = int(gold["N"]), int(gold["steps"]), float(gold["dt"]), float(gold["Rm"])
+    assert (N, n) == (128, 1000)
+    dom = kdyn.KDynDomain(N)
+    B, U = _bench_fields(dom.G)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    for cost in ("Final", "Integrated"):
+        if "%s_Discrete_gB" % cost not in gold.files:
+            continue
+        args = [dom, Rm, dt, n, n, buf, cost, "Discrete"]
+        J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+        gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        _check_against_fixture(gold, "%s_Discrete" % cost, J, gB, gU)
+        if cost == "Final":
+            for k in (n // 4, n // 2, n):
+                snap = dom.context(Rm, dt, n, cost).snapshot(k).view(np.complex128)
+                ref = float(gold["snap_%d_norm" % k])
+                assert abs(np.linalg.norm(snap) - ref) <= 1e-9 * ref
+                assert np.linalg.norm(snap[::9973] - gold["snap_%d_sample" % k]) <= 1e-9 * np.linalg.norm(gold["snap_%d_sample" % k])
+        dom.drop_contexts()
+
+
 def test_config5_fixture():
     """BASELINE configs[4]'s grid (256^3: the G = 384 kernel instantiations — half tiles, half twiddle table, narrower adjoint x tiles)
     on ONE GPU against the oracle: tests/golden/oracle_kdyn_c5_256_n2.npz, all four combinations."""
