@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "smo_common.hpp"
+#include "hodlr.hpp"
 
 namespace smo {
 namespace {
@@ -162,6 +163,74 @@ __global__ __launch_bounds__(256) void pois_apply(const double2* __restrict__ S,
             xout_v[(size_t)(2 * n) * 3 + (r - nout * Nz)] = yr; xout_v[(size_t)(2 * n + 1) * 3 + (r - nout * Nz)] = yi;
         }
     }
+    }
+}
+// The same operators in HODLR form (hodlr.hpp): rows and columns mode-major (index 3*mode + variable), every off-diagonal block a
+// rank <= 16 product.  One workgroup per (wavenumber, task = tree node at the split depth); lane groups of 8 take the descriptor rows
+// round-robin, every row a contiguous, 128-byte aligned run of the operator stream against a contiguous run of the LDS array Z:
+//   round 1  t_b = V_b^H x          (the blocks over and under the task's node)
+//   copy     G_leaf = [x_leaf | t_b of the blocks over the leaf | extras]
+//   round 2  y_r = [D_r | U_b,r ... | extras_r] . G_leaf(r)
+// 1.24 MB per wavenumber instead of 4.1 MB at Nz = 192.  Nothing is sequential along the mode index.
+__device__ __forceinline__ double2 hodlr_dot(const double2* __restrict__ d, const double2* z, int len, int l) {
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+    int i = l;
+    for (; i + 32 - l <= len; i += 32) {                    // four independent 16-byte loads per lane in flight
+        const double2 s0 = d[i], s1 = d[i + 8], s2 = d[i + 16], s3 = d[i + 24];
+        const double2 x0 = z[i], x1 = z[i + 8], x2 = z[i + 16], x3 = z[i + 24];
+        ar += s0.x * x0.x - s0.y * x0.y; ai += s0.x * x0.y + s0.y * x0.x;
+        br += s1.x * x1.x - s1.y * x1.y; bi += s1.x * x1.y + s1.y * x1.x;
+        ar += s2.x * x2.x - s2.y * x2.y; ai += s2.x * x2.y + s2.y * x2.x;
+        br += s3.x * x3.x - s3.y * x3.y; bi += s3.x * x3.y + s3.y * x3.x;
+    }
+    for (; i < len; i += 8) {
+        const double2 s0 = d[i], x0 = z[i];
+        ar += s0.x * x0.x - s0.y * x0.y; ai += s0.x * x0.y + s0.y * x0.x;
+    }
+    ar += br; ai += bi;
+    for (int off = 4; off > 0; off >>= 1) { ar += __shfl_xor(ar, off); ai += __shfl_xor(ai, off); }
+    return double2{ar, ai};
+}
+__global__ __launch_bounds__(256) void pois_apply_hodlr(const double2* __restrict__ data, size_t stride, const hodlr::Row* __restrict__ rows,
+                                                        const uint16_t* __restrict__ lut, const hodlr::Task* __restrict__ tasks, int modes,
+                                                        const double* __restrict__ in, const double* __restrict__ xin_v, double* __restrict__ out,
+                                                        double* __restrict__ xout_v, double* __restrict__ snap, int a, int Nz, int xin) {
+    extern __shared__ double2 Z[];
+    // tasks of one wavenumber `modes` blocks apart: the same XCD (modes is a multiple of 8 at the sizes that matter), so the V^H rows of
+    // the blocks above the split level, which every task under them reads, come from that XCD's L2 the second time
+    const int n = blockIdx.x % modes, w = blockIdx.x / modes;
+    const hodlr::Task T = tasks[w];
+    const int n3 = 3 * Nz, l = threadIdx.x & 7, g = threadIdx.x >> 3;
+    for (int i = n3 + xin + threadIdx.x; i < (int)T.zend; i += 256) Z[i] = double2{0.0, 0.0};
+    for (int c = threadIdx.x; c < n3; c += 256) {
+        const int fi = c / Nz, j = c - fi * Nz;
+        const size_t e = ((size_t)fi * 2 * a + 2 * n) * Nz + j;
+        Z[3 * j + fi] = double2{in[e], in[e + Nz]};
+    }
+    if ((int)threadIdx.x < xin) Z[n3 + threadIdx.x] = double2{xin_v[(size_t)(2 * n) * 3 + threadIdx.x], xin_v[(size_t)(2 * n + 1) * 3 + threadIdx.x]};
+    __syncthreads();
+    const double2* base = data + (size_t)n * stride;
+    for (int r = g; r < (int)T.n1; r += 32) {
+        const hodlr::Row R = rows[T.row1 + r];
+        const double2 t = hodlr_dot(base + R.data, Z + R.in, R.len, l);
+        if (l == 0) Z[R.out] = t;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)T.nlut; i += 256) Z[T.zg + i] = Z[lut[T.lut + i]];
+    __syncthreads();
+    for (int r = g; r < (int)T.n2; r += 32) {
+        const hodlr::Row R = rows[T.row2 + r];
+        const double2 y = hodlr_dot(base + R.data, Z + R.in, R.len, l);
+        if (l == 0) {
+            if ((int)R.out < n3) {
+                const int j = R.out / 3, fo = R.out - 3 * j;
+                const size_t o = ((size_t)fo * 2 * a + 2 * n) * Nz + j;
+                out[o] = y.x; out[o + Nz] = y.y;
+                if (snap) { snap[o] = y.x; snap[o + Nz] = y.y; }
+            } else {
+                xout_v[(size_t)(2 * n) * 3 + (R.out - n3)] = y.x; xout_v[(size_t)(2 * n + 1) * 3 + (R.out - n3)] = y.y;
+            }
+        }
     }
 }
 // The z-derivative variables of the tau system differ from the T-space derivative of u, v, rho only along q = Pre^-1 e_{N-1}
@@ -453,11 +522,18 @@ public:
     double *d_Wz = nullptr, *d_rho0 = nullptr, *d_rz0 = nullptr;
     double2 *d_S = nullptr, *d_SH = nullptr, *d_SMN = nullptr, *d_SMNH = nullptr;   // d_S: (3Nz+3) x 3Nz per wavenumber, d_SH its conjugate transpose
     double *d_q = nullptr, *d_X3 = nullptr;                                         // q = Pre^-1 e_{N-1} (q_{N-1} = 1); extras [2a][3]
+    // HODLR form of the same two operators (the default; SMO_POIS_APPLY=dense keeps the dense stream above instead)
+    struct HOp { double2* data = nullptr; hodlr::Row* rows = nullptr; uint16_t* lut = nullptr; hodlr::Task* tasks = nullptr;
+                 size_t stride = 0; int W = 0, xin = 0; unsigned lds = 0; };
+    HOp hF, hA;
+    bool use_hodlr = true;
+    int hodlr_max_rank = 0;
     // work
     double *S6 = nullptr, *R3 = nullptr, *L6 = nullptr, *A3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr,
            *HC = nullptr, *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     int k_gemm = -1, k_apply = -1, k_point = -1;
+    double op_bytes = 0.0;
 
     struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
     Phase F0x, F0z, F0d, F1d, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
@@ -479,6 +555,29 @@ public:
         ScopedTimer t(timing, k_apply, stream);
         hipLaunchKernelGGL(pois_apply, dim3((unsigned)(modes * ((rows + APPLY_ROWS - 1) / APPLY_ROWS))), dim3(256), cols * sizeof(double2), stream, S, in, xin_v, out, xout_v,
                            snap, a, modes, Nz, nin, xin, nout, xout, structure);
+        return SMO_OK;
+    }
+    int apply_hodlr(const HOp& h, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int modes) {
+        ScopedTimer t(timing, k_apply, stream);
+        hipLaunchKernelGGL(pois_apply_hodlr, dim3((unsigned)(modes * h.W)), dim3(256), h.lds, stream, h.data, h.stride, h.rows, h.lut, h.tasks, modes, in,
+                           xin_v, out, xout_v, snap, a, Nz, h.xin);
+        return SMO_OK;
+    }
+    // the step's tau solve and its transpose
+    int solve_fwd(int n) {
+        return use_hodlr ? apply_hodlr(hF, R3, nullptr, S6, d_X3, snap(n + 1), ada) : apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada, 1);
+    }
+    int solve_adj() {
+        return use_hodlr ? apply_hodlr(hA, R3, d_X3, A3, nullptr, nullptr, a) : apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2);
+    }
+    int upload_hop(HOp& h, const hodlr::Layout& L, const std::vector<cd>& data) {
+        h.stride = L.stride; h.W = L.W; h.xin = L.xin; h.lds = L.lds_entries * (unsigned)sizeof(double2);
+        if (h.lds > 160u * 1024u) { set_error("POIS: the HODLR apply needs %u bytes of LDS", h.lds); return SMO_ERR_UNSUPPORTED; }
+        if (h.lds > 64u * 1024u) SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pois_apply_hodlr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds));
+        SMO_TRY(pool.alloc(&h.data, data.size()));
+        SMO_HIP(hipMemcpyAsync(h.data, data.data(), data.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+        SMO_HIP(hipStreamSynchronize(stream));
+        SMO_TRY(pool.upload(&h.rows, L.rows, stream)); SMO_TRY(pool.upload(&h.lut, L.lut, stream)); SMO_TRY(pool.upload(&h.tasks, L.tasks, stream));
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
@@ -575,29 +674,55 @@ public:
         }
         // ---- tau operators, one per wavenumber, built by host threads ---------------------------------------------------------------------
         {
-            const size_t sz = (size_t)(3 * N + 3) * 3 * N, szm = (size_t)2 * N * N;
-            std::vector<cd> S((size_t)a * sz), SH((size_t)a * sz), SM((size_t)a * szm), SMH((size_t)a * szm);
+            const char* mode = getenv("SMO_POIS_APPLY");
+            use_hodlr = !(mode && std::string(mode) == "dense");
+            if (mode && use_hodlr && std::string(mode) != "hodlr") { set_error("SMO_POIS_APPLY must be hodlr or dense, got %s", mode); return SMO_ERR_ARG; }
+            const int n3 = 3 * N;
+            const size_t sz = (size_t)(n3 + 3) * n3, szm = (size_t)2 * N * N;
+            std::vector<cd> S, SH, SM((size_t)a * szm), SMH((size_t)a * szm);
+            if (!use_hodlr) { S.resize((size_t)a * sz); SH.resize((size_t)a * sz); }
+            const hodlr::Plan plan = hodlr::make_plan(n3);
+            std::vector<hodlr::Factors> fac(use_hodlr ? a : 0);
+            std::vector<std::vector<cd>> extras(use_hodlr ? a : 0);
+            const double rel_tol = getenv("SMO_POIS_HODLR_TOL") ? atof(getenv("SMO_POIS_HODLR_TOL")) : 1e-14;
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
             const int nthr = std::max(1, std::min<int>(std::min(a, 32), (int)std::thread::hardware_concurrency()));   // one wavenumber per task; <= 32 host threads
             auto work = [&](int t) {
+                std::vector<cd> red(sz), perm;
                 for (int n = t; n < a; n += nthr) {
                     std::vector<cd> s, sm;
                     int r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, s);
                     if (r == SMO_OK) r = build_mixnorm_map(ch, n, k1 * n, sm);
                     if (r != SMO_OK) { rc[n] = r; msg[n] = last_error(); continue; }
                     // keep the rows of u, v, rho and the last row of each derivative variable (see pois_rank1_add)
-                    cd* dst = &S[(size_t)n * sz];
-                    std::copy(s.begin(), s.begin() + (size_t)3 * N * 3 * N, dst);
-                    for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * 3 * N], &s[((size_t)(3 + f) * N + N - 1) * 3 * N] + 3 * N, dst + (size_t)(3 * N + f) * 3 * N);
+                    cd* dst = use_hodlr ? red.data() : &S[(size_t)n * sz];
+                    std::copy(s.begin(), s.begin() + (size_t)n3 * n3, dst);
+                    for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * n3], &s[((size_t)(3 + f) * N + N - 1) * n3] + n3, dst + (size_t)(n3 + f) * n3);
                     std::copy(sm.begin(), sm.end(), SM.begin() + (size_t)n * szm);
-                    for (int i = 0; i < 3 * N + 3; ++i) for (int j = 0; j < 3 * N; ++j) SH[(size_t)n * sz + (size_t)j * (3 * N + 3) + i] = std::conj(dst[(size_t)i * 3 * N + j]);
                     for (int i = 0; i < 2 * N; ++i) for (int j = 0; j < N; ++j) SMH[(size_t)n * szm + (size_t)j * 2 * N + i] = std::conj(sm[(size_t)i * N + j]);
+                    if (!use_hodlr) {
+                        for (int i = 0; i < n3 + 3; ++i) for (int j = 0; j < n3; ++j) SH[(size_t)n * sz + (size_t)j * (n3 + 3) + i] = std::conj(dst[(size_t)i * n3 + j]);
+                        continue;
+                    }
+                    // mode-major ordering (index 3*mode + variable) of rows and columns, then the HODLR factors (hodlr.hpp)
+                    perm.resize((size_t)n3 * n3);
+                    extras[n].resize((size_t)3 * n3);
+                    double mx = 0.0;
+                    for (int v = 0; v < 3; ++v) for (int j = 0; j < N; ++j) {
+                        const cd* row = dst + (size_t)(v * N + j) * n3;
+                        cd* prow = &perm[(size_t)(3 * j + v) * n3];
+                        for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) { prow[3 * i + w] = row[w * N + i]; mx = std::max(mx, std::abs(row[w * N + i])); }
+                    }
+                    for (int e = 0; e < 3; ++e) for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) extras[n][(size_t)e * n3 + 3 * i + w] = dst[(size_t)(n3 + e) * n3 + w * N + i];
+                    hodlr::factor(plan, perm.data(), n3, rel_tol * mx, fac[n]);
                 }
             };
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
-            for (auto& t : th) t.join();
+            {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+                for (auto& t : th) t.join();
+            }
             for (int n = 0; n < a; ++n) if (rc[n] != SMO_OK) { set_error("%s (wavenumber %d)", msg[n].c_str(), n); return rc[n]; }
             auto up = [&](double2** p, const std::vector<cd>& h) -> int {
                 SMO_TRY(pool.alloc(p, h.size()));
@@ -605,7 +730,33 @@ public:
                 SMO_HIP(hipStreamSynchronize(stream));
                 return SMO_OK;
             };
-            SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SH, SH)); SMO_TRY(up(&d_SMN, SM)); SMO_TRY(up(&d_SMNH, SMH));
+            SMO_TRY(up(&d_SMN, SM)); SMO_TRY(up(&d_SMNH, SMH));
+            if (!use_hodlr) {
+                SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SH, SH));
+                op_bytes = 0.5 * (double)(ada + a) * (double)sz * 16.0;
+            } else {
+                // one set of descriptors for all wavenumbers: every block gets the largest rank found for it
+                std::vector<int> K(plan.blocks.size(), 0), KH(plan.blocks.size(), 0);
+                for (int n = 0; n < a; ++n) for (size_t b = 0; b < K.size(); ++b) K[b] = std::max(K[b], fac[n].rank[b]);
+                for (size_t b = 0; b < K.size(); ++b) { KH[b] = K[plan.blocks[b].pair]; hodlr_max_rank = std::max(hodlr_max_rank, K[b]); }
+                // workgroups per wavenumber = tree nodes at this depth.  384 x 192 (MI355X): depth 1 52 us per launch, 2: 41, 3: 40, 4: 46 (the V^H
+                // rows of the blocks above the split are read by every task under them; below depth 3 there are too few workgroups)
+                const int split = getenv("SMO_POIS_HODLR_SPLIT") ? atoi(getenv("SMO_POIS_HODLR_SPLIT")) : 3;
+                if (split < 0 || split > 6) { set_error("SMO_POIS_HODLR_SPLIT must be in [0, 6]"); return SMO_ERR_ARG; }
+                const hodlr::Layout Lf = hodlr::make_layout(plan, K, split, 0, 3), La = hodlr::make_layout(plan, KH, split, 3, 0);
+                std::vector<cd> df((size_t)ada * Lf.stride), da((size_t)a * La.stride);
+                auto packer = [&](int t) {
+                    for (int n = t; n < a; n += nthr) {
+                        if (n < ada) hodlr::pack(plan, Lf, fac[n], extras[n].data(), false, &df[(size_t)n * Lf.stride]);
+                        hodlr::pack(plan, La, fac[n], extras[n].data(), true, &da[(size_t)n * La.stride]);
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 0; t < nthr; ++t) th.emplace_back(packer, t);
+                for (auto& t : th) t.join();
+                SMO_TRY(upload_hop(hF, Lf, df)); SMO_TRY(upload_hop(hA, La, da));
+                op_bytes = 0.5 * ((double)ada * Lf.stride + (double)a * La.stride) * 16.0;
+            }
         }
         // ---- work buffers -----------------------------------------------------------------------------------------------
         SMO_TRY(pool.alloc(&S6, 6 * nC)); SMO_TRY(pool.alloc(&R3, 3 * nC)); SMO_TRY(pool.alloc(&L6, 6 * nC)); SMO_TRY(pool.alloc(&A3, 3 * nC));
@@ -660,9 +811,9 @@ public:
         SMO_TRY(make_phase(Gd, M2a, Nz, Nz, {{c_(L6, 3), B_Dz, c_(HC, 0)}, {c_(L6, 4), B_Dz, c_(HC, 1)}}));
         SMO_TRY(make_phase(Gz, M2a, Nz, Nz, {{c_(L6, 0), B_Zf, c_(G1, 0)}, {c_(L6, 1), B_Zf, c_(G1, 1)}}));
         SMO_TRY(make_phase(Gx, Nx, Nz, M2a, {{A_XiN, c_(G1, 0), g_(GR, 0)}, {A_XiN, c_(G1, 1), g_(GR, 1)}}));
-        const double op_bytes = (double)ada * (3 * N + 3) * 3 * N * 16.0;
         k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
-        k_apply = timing.add_class("pois_apply (tau operator, batched complex GEMV)", op_bytes);
+        // bytes of the operators one launch streams: the mean of the forward (de-aliased wavenumbers) and the transposed apply (all of them)
+        k_apply = timing.add_class(use_hodlr ? "pois_apply_hodlr (tau operator, HODLR form)" : "pois_apply (tau operator, batched complex GEMV)", op_bytes, op_bytes);
         k_point = timing.add_class("pois pointwise", 0.0);
         return SMO_OK;
     }
@@ -698,7 +849,7 @@ public:
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, S6, 1.0 / cfg.dt, HC, 3 * nC);
             }
-            SMO_TRY(apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada, 1));
+            SMO_TRY(solve_fwd(n));
             SMO_TRY(run(F1d));                                               // uz, vz, rhoz = (u, v, rho) Dz^T + last coefficient * q
             {
                 ScopedTimer t(timing, k_point, stream);
@@ -776,7 +927,7 @@ public:
                 hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
                 hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, L6, 1.0, HC, 3 * nC);
             }
-            SMO_TRY(apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2));
+            SMO_TRY(solve_adj());
             SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
             SMO_TRY(run(Az)); SMO_TRY(run(Ax));
             {

@@ -154,3 +154,32 @@ def test_reference_resolution_properties():
     div = 1j * k[:, None] * u + w @ D.T
     assert np.abs(div[:, :Nz - 2]).max() < 1e-6 * np.abs(w @ D.T).max()
     dom.drop_contexts()
+
+
+@pytest.mark.parametrize("Nx,Nz,n,s,split", [(48, 36, 6, 1, 2), (96, 48, 5, 0, 1), (30, 66, 5, 1, 3), (384, 192, 12, 1, 2), (384, 192, 4, 0, 0), (96, 384, 3, 1, 3)])
+def test_hodlr_apply_matches_dense_apply(Nx, Nz, n, s, split, monkeypatch):
+    """The tau operators in HODLR form (csrc/hodlr.hpp, the default) against the dense operator stream they replace (SMO_POIS_APPLY=dense):
+    cost, gradient and snapshots to 1e-11, for several task splits and non-power-of-two trees; ranks stay the structural ones."""
+    _, U0 = pz.Generate_IC(Nx, Nz, E_0=0.02, seed=3)
+    res = {}
+    for mode in ("dense", "hodlr"):
+        monkeypatch.setenv("SMO_POIS_APPLY", mode)
+        monkeypatch.setenv("SMO_POIS_HODLR_SPLIT", str(split))
+        dom = pz.PoiseuilleDomain(Nx, Nz)
+        buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+        args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.125]
+        J = pz.FWD_Solve_Discrete(U0, *args)
+        g = pz.ADJ_Solve_Discrete(U0, *args)[0]
+        res[mode] = (J, g, buf['u_fwd'][:, :, -1].copy(), buf['b_fwd'][:, :, -1].copy())
+        dom.drop_contexts()
+    (Jd, gd, ud, bd), (Jh, gh, uh, bh) = res["dense"], res["hodlr"]
+    assert abs(Jh - Jd) <= 1e-11 * abs(Jd), (Jh, Jd)
+    assert rel(gh, gd) < 1e-11 and rel(uh, ud) < 1e-11 and rel(bh, bd) < 1e-11, (rel(gh, gd), rel(uh, ud), rel(bh, bd))
+
+
+def test_apply_mode_knob_is_validated(monkeypatch):
+    monkeypatch.setenv("SMO_POIS_APPLY", "banded")
+    dom = pz.PoiseuilleDomain(24, 24)
+    with pytest.raises(Exception):
+        dom.context(500., 0.05, 2, 5e-3, 0, 1., 0.125)
+    dom.drop_contexts()
