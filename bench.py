@@ -93,7 +93,6 @@ def bench_sh23(a, torch, rank, world):
     Gd = torch.empty_like(Xd)
     for _ in range(warm):
         ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
-    ctx.timing_enable(True)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -104,6 +103,9 @@ def bench_sh23(a, torch, rank, world):
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
+    ctx.timing_enable(True)                             # the per-kernel figures come from one more gradient, outside the timed region (an event pair per launch costs time)
+    ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    torch.cuda.synchronize()
     tim = ctx.timing()
     dom_k = max(tim, key=lambda t: t["total_ms"])
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
@@ -194,12 +196,13 @@ def bench_pois(a, torch, rank, world):
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     tim = ctx.timing()
-    dom_k = max(tim, key=lambda t: t["total_ms"])
+    dom_k = max(tim, key=lambda t: t["total_ms"] if t["bytes_per_launch"] > 0 else -1.0)     # the HBM-bound kernel: the operator apply (the MFMA GEMMs are launch-bound)
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1)} for t in tim],
-            "note": "bytes_per_launch = the tau operators of the de-aliased wavenumbers (forward apply); the adjoint apply streams 1.5x that"}
+            "note": "bytes_per_launch = the tau operators one launch streams (HODLR form; the mean of the forward apply over the de-aliased "
+                    "wavenumbers and the transposed apply over all of them)"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     cfg = {"workload": "Plane-Poiseuille optimal mixing (Discrete), Nx x Nz = %d x %d, Re=500, Ri=0.05, T=%g, dt=%g, mix-norm cost"
                        % (Nx, Nz, dt * n_iters, dt),

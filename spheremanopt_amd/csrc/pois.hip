@@ -34,16 +34,20 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // batched C = A * B (row-major, dense leading dimensions), fp64 MFMA 16x16x4; 32-deep K slices staged through LDS with the next slice
 // prefetched into registers
 // ---------------------------------------------------------------------------------------------------------
-struct GemmDesc { const double* A; const double* B; double* C; };
+// optional epilogue: C = A B + alpha * E + X (x) Q   (E laid out like C; X one value per row with stride 3, Q one per column: the rank-one tau
+// correction of the z-derivative variables); dyn: A is moved by the launch's `shift` doubles (the snapshot the adjoint step linearises about)
+struct GemmDesc { const double* A; const double* B; double* C; const double* E = nullptr; double alpha = 0.0; const double* X = nullptr;
+                  const double* Q = nullptr; int dyn = 0; };
 
 // TM x TN tile per workgroup (4 waves as 2 x 2, each (TM/2) x (TN/2) = MI x NI MFMA tiles).  The products of this path are small
 // (M, N, K of a few hundred, 2-17 of them per launch): 32 x 32 tiles give 4x more workgroups than 64 x 64 and keep the 256 CUs busy.
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ descs, int M, int N, int K) {
+__global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ descs, int M, int N, int K, long long shift) {
     constexpr int KT = 32;                                   // K slice per LDS stage
     constexpr int MI = TM / 32, NI = TN / 32, NA = TM * KT / 256, NBL = KT * TN / 256;
     static_assert(TM % 32 == 0 && TN % 32 == 0, "tile = multiples of 32");
-    const GemmDesc d = descs[blockIdx.z];
+    GemmDesc d = descs[blockIdx.z];
+    if (d.dyn) d.A += shift;
     __shared__ double As[TM][KT + 1];
     __shared__ double Bs[KT][TN + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -100,12 +104,17 @@ __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ de
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                            // C: col = lane&15, row = (lane>>4) + 4*reg
                 const int row = m0 + wm + 16 * i + lk + 4 * r, col = n0 + wn + 16 * j + lr;
-                if (row < M && col < N) d.C[(size_t)row * N + col] = acc[i][j][r];
+                if (row < M && col < N) {
+                    double v = acc[i][j][r];
+                    if (d.E) v += d.alpha * d.E[(size_t)row * N + col];
+                    if (d.X) v += d.X[(size_t)row * 3] * d.Q[col];
+                    d.C[(size_t)row * N + col] = v;
+                }
             }
 }
 constexpr int GEMM_T = 32;
-static inline void launch_gemm(hipStream_t stream, const GemmDesc* descs, int n, int M, int N, int K) {
-    hipLaunchKernelGGL((pois_gemm<GEMM_T, GEMM_T>), dim3((N + GEMM_T - 1) / GEMM_T, (M + GEMM_T - 1) / GEMM_T, n), dim3(256), 0, stream, descs, M, N, K);
+static inline void launch_gemm(hipStream_t stream, const GemmDesc* descs, int n, int M, int N, int K, long long shift = 0) {
+    hipLaunchKernelGGL((pois_gemm<GEMM_T, GEMM_T>), dim3((N + GEMM_T - 1) / GEMM_T, (M + GEMM_T - 1) / GEMM_T, n), dim3(256), 0, stream, descs, M, N, K, shift);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -194,7 +203,8 @@ __device__ __forceinline__ double2 hodlr_dot(const double2* __restrict__ d, cons
 __global__ __launch_bounds__(256) void pois_apply_hodlr(const double2* __restrict__ data, size_t stride, const hodlr::Row* __restrict__ rows,
                                                         const uint16_t* __restrict__ lut, const hodlr::Task* __restrict__ tasks, int modes,
                                                         const double* __restrict__ in, const double* __restrict__ xin_v, double* __restrict__ out,
-                                                        double* __restrict__ xout_v, double* __restrict__ snap, int a, int Nz, int xin) {
+                                                        double* __restrict__ xout_v, double* __restrict__ snap, int a, int Nz, int xin,
+                                                        const double* __restrict__ xsrc, const double* __restrict__ q) {
     extern __shared__ double2 Z[];
     // tasks of one wavenumber `modes` blocks apart: the same XCD (modes is a multiple of 8 at the sizes that matter), so the V^H rows of
     // the blocks above the split level, which every task under them reads, come from that XCD's L2 the second time
@@ -207,7 +217,21 @@ __global__ __launch_bounds__(256) void pois_apply_hodlr(const double2* __restric
         const size_t e = ((size_t)fi * 2 * a + 2 * n) * Nz + j;
         Z[3 * j + fi] = double2{in[e], in[e + Nz]};
     }
-    if ((int)threadIdx.x < xin) Z[n3 + threadIdx.x] = double2{xin_v[(size_t)(2 * n) * 3 + threadIdx.x], xin_v[(size_t)(2 * n + 1) * 3 + threadIdx.x]};
+    if (xsrc) {
+        // the three extra inputs of the transposed operator, x_e = q . lambda_e (lambda_e: the fields of the derivative variables, rows 2n / 2n+1 of
+        // xsrc[e]): six dot products of Nz terms, one per 32 lanes (pois_rank1_dot as part of this launch)
+        const int dgrp = threadIdx.x >> 5, dl = threadIdx.x & 31;
+        if (dgrp < 2 * xin) {
+            const int e = dgrp >> 1, part = dgrp & 1;
+            const double* src = xsrc + ((size_t)e * 2 * a + 2 * n + part) * Nz;
+            double acc = 0.0;
+            for (int j = dl; j < Nz; j += 32) acc += q[j] * src[j];
+            for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (dl == 0) { if (part == 0) Z[n3 + e].x = acc; else Z[n3 + e].y = acc; }
+        }
+    } else if ((int)threadIdx.x < xin) {
+        Z[n3 + threadIdx.x] = double2{xin_v[(size_t)(2 * n) * 3 + threadIdx.x], xin_v[(size_t)(2 * n + 1) * 3 + threadIdx.x]};
+    }
     __syncthreads();
     const double2* base = data + (size_t)n * stride;
     for (int r = g; r < (int)T.n1; r += 32) {
@@ -507,6 +531,67 @@ static int build_mixnorm_map(const Cheb& ch, int n, double k, std::vector<cd>& S
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// HODLR operator sets on the device (hodlr.hpp): shared by the Discrete and the Continuous formulation
+// ---------------------------------------------------------------------------------------------------------
+struct HOp { double2* data = nullptr; hodlr::Row* rows = nullptr; uint16_t* lut = nullptr; hodlr::Task* tasks = nullptr;
+             size_t stride = 0; int W = 0, xin = 0, max_rank = 0; unsigned lds = 0; };
+
+static int pois_apply_mode(bool* use_hodlr) {             // SMO_POIS_APPLY = hodlr (default) | dense (the dense operator stream, kept as the test reference)
+    const char* mode = getenv("SMO_POIS_APPLY");
+    *use_hodlr = !(mode && std::string(mode) == "dense");
+    if (mode && *use_hodlr && std::string(mode) != "hodlr") { set_error("SMO_POIS_APPLY must be hodlr or dense, got %s", mode); return SMO_ERR_ARG; }
+    return SMO_OK;
+}
+// a reduced operator ((3N + 3) x 3N, rows and columns variable-major: the rows of u, v, rho and the three extra rows) -> mode-major
+// ordering (index 3*mode + variable) of the square part, its HODLR factors, and the extra rows in the same column order
+static void hodlr_factor_reduced(const hodlr::Plan& plan, const cd* red, int N, std::vector<cd>& perm, hodlr::Factors& f, std::vector<cd>& extras) {
+    const int n3 = 3 * N;
+    const double rel_tol = getenv("SMO_POIS_HODLR_TOL") ? atof(getenv("SMO_POIS_HODLR_TOL")) : 1e-14;
+    perm.resize((size_t)n3 * n3);
+    extras.resize((size_t)3 * n3);
+    double mx = 0.0;
+    for (int v = 0; v < 3; ++v) for (int j = 0; j < N; ++j) {
+        const cd* row = red + (size_t)(v * N + j) * n3;
+        cd* prow = &perm[(size_t)(3 * j + v) * n3];
+        for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) { prow[3 * i + w] = row[w * N + i]; mx = std::max(mx, std::abs(row[w * N + i])); }
+    }
+    for (int e = 0; e < 3; ++e) for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) extras[(size_t)e * n3 + 3 * i + w] = red[(size_t)(n3 + e) * n3 + w * N + i];
+    hodlr::factor(plan, perm.data(), n3, rel_tol * mx, f);
+}
+// pack the first `count` operators (or their conjugate transposes) with one set of descriptors — every block gets the largest rank found
+// for it in any of the operators — and upload them
+static int hop_build(DevPool& pool, hipStream_t stream, const hodlr::Plan& plan, const std::vector<hodlr::Factors>& fac, const std::vector<std::vector<cd>>& extras,
+                     int count, bool adjoint, int nthr, HOp& h, double* bytes) {
+    std::vector<int> K(plan.blocks.size(), 0), KH(plan.blocks.size(), 0);
+    for (const hodlr::Factors& f : fac) for (size_t b = 0; b < K.size(); ++b) K[b] = std::max(K[b], f.rank[b]);
+    for (size_t b = 0; b < K.size(); ++b) { KH[b] = K[plan.blocks[b].pair]; h.max_rank = std::max(h.max_rank, K[b]); }
+    // workgroups per wavenumber = tree nodes at this depth.  384 x 192 (MI355X): depth 1 52 us per launch, 2: 41, 3: 40, 4: 46 (the V^H
+    // rows of the blocks above the split are read by every task under them; below depth 3 there are too few workgroups)
+    const int split = getenv("SMO_POIS_HODLR_SPLIT") ? atoi(getenv("SMO_POIS_HODLR_SPLIT")) : 3;
+    if (split < 0 || split > 6) { set_error("SMO_POIS_HODLR_SPLIT must be in [0, 6]"); return SMO_ERR_ARG; }
+    const hodlr::Layout L = adjoint ? hodlr::make_layout(plan, KH, split, 3, 0) : hodlr::make_layout(plan, K, split, 0, 3);
+    std::vector<cd> data((size_t)count * L.stride);
+    auto packer = [&](int t) { for (int n = t; n < count; n += nthr) hodlr::pack(plan, L, fac[n], extras[n].data(), adjoint, &data[(size_t)n * L.stride]); };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) th.emplace_back(packer, t);
+    for (auto& t : th) t.join();
+    h.stride = L.stride; h.W = L.W; h.xin = L.xin; h.lds = L.lds_entries * (unsigned)sizeof(double2);
+    if (h.lds > 160u * 1024u) { set_error("POIS: the HODLR apply needs %u bytes of LDS", h.lds); return SMO_ERR_UNSUPPORTED; }
+    if (h.lds > 64u * 1024u) SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pois_apply_hodlr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds));
+    SMO_TRY(pool.alloc(&h.data, data.size()));
+    SMO_HIP(hipMemcpyAsync(h.data, data.data(), data.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
+    SMO_HIP(hipStreamSynchronize(stream));
+    SMO_TRY(pool.upload(&h.rows, L.rows, stream)); SMO_TRY(pool.upload(&h.lut, L.lut, stream)); SMO_TRY(pool.upload(&h.tasks, L.tasks, stream));
+    *bytes = (double)count * (double)L.stride * 16.0;
+    return SMO_OK;
+}
+static inline void hop_launch(const HOp& h, hipStream_t stream, int modes, const double* in, const double* xin_v, double* out, double* xout_v, double* snap,
+                              int a, int Nz, const double* xsrc = nullptr, const double* q = nullptr) {
+    hipLaunchKernelGGL(pois_apply_hodlr, dim3((unsigned)(modes * h.W)), dim3(256), h.lds, stream, h.data, h.stride, h.rows, h.lut, h.tasks, modes, in, xin_v,
+                       out, xout_v, snap, a, Nz, h.xin, xsrc, q);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
 class Pois : public Context {
@@ -521,13 +606,10 @@ public:
     double *A_Xi = nullptr, *A_XiD = nullptr, *A_XiN = nullptr, *A_XiN_DA = nullptr, *A_Xf = nullptr, *A_Xf_DA = nullptr, *A_XfN = nullptr, *A_XfNDa = nullptr;
     double *d_Wz = nullptr, *d_rho0 = nullptr, *d_rz0 = nullptr;
     double2 *d_S = nullptr, *d_SH = nullptr, *d_SMN = nullptr, *d_SMNH = nullptr;   // d_S: (3Nz+3) x 3Nz per wavenumber, d_SH its conjugate transpose
+    double *d_qz = nullptr;                                                         // q on the Gauss grid: qz[z] = sum_j Ti[z][j] q[j]
     double *d_q = nullptr, *d_X3 = nullptr;                                         // q = Pre^-1 e_{N-1} (q_{N-1} = 1); extras [2a][3]
-    // HODLR form of the same two operators (the default; SMO_POIS_APPLY=dense keeps the dense stream above instead)
-    struct HOp { double2* data = nullptr; hodlr::Row* rows = nullptr; uint16_t* lut = nullptr; hodlr::Task* tasks = nullptr;
-                 size_t stride = 0; int W = 0, xin = 0; unsigned lds = 0; };
-    HOp hF, hA;
+    HOp hF, hA;                                                                     // the same two operators in HODLR form (the default)
     bool use_hodlr = true;
-    int hodlr_max_rank = 0;
     // work
     double *S6 = nullptr, *R3 = nullptr, *L6 = nullptr, *A3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr,
            *HC = nullptr, *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
@@ -536,16 +618,16 @@ public:
     double op_bytes = 0.0;
 
     struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
-    Phase F0x, F0z, F0d, F1d, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
+    Phase F0x, F0z, F0d, Fz1, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
 
     int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
         p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
         return pool.upload(&p.d, v, stream);
     }
-    int run(const Phase& p, int count = -1) {
+    int run(const Phase& p, int count = -1, long long shift = 0) {
         const int n = count < 0 ? p.n : count;
         ScopedTimer t(timing, k_gemm, stream);
-        launch_gemm(stream, p.d, n, p.M, p.N, p.K);
+        launch_gemm(stream, p.d, n, p.M, p.N, p.K, shift);
         return SMO_OK;
     }
     // `modes`: apply the operators of n = 0..modes-1 only (the forward state is zero beyond the de-aliased modes)
@@ -559,8 +641,7 @@ public:
     }
     int apply_hodlr(const HOp& h, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int modes) {
         ScopedTimer t(timing, k_apply, stream);
-        hipLaunchKernelGGL(pois_apply_hodlr, dim3((unsigned)(modes * h.W)), dim3(256), h.lds, stream, h.data, h.stride, h.rows, h.lut, h.tasks, modes, in,
-                           xin_v, out, xout_v, snap, a, Nz, h.xin);
+        hop_launch(h, stream, modes, in, xin_v, out, xout_v, snap, a, Nz);
         return SMO_OK;
     }
     // the step's tau solve and its transpose
@@ -568,16 +649,9 @@ public:
         return use_hodlr ? apply_hodlr(hF, R3, nullptr, S6, d_X3, snap(n + 1), ada) : apply(d_S, R3, nullptr, S6, d_X3, snap(n + 1), 3, 0, 3, 3, ada, 1);
     }
     int solve_adj() {
-        return use_hodlr ? apply_hodlr(hA, R3, d_X3, A3, nullptr, nullptr, a) : apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2);
-    }
-    int upload_hop(HOp& h, const hodlr::Layout& L, const std::vector<cd>& data) {
-        h.stride = L.stride; h.W = L.W; h.xin = L.xin; h.lds = L.lds_entries * (unsigned)sizeof(double2);
-        if (h.lds > 160u * 1024u) { set_error("POIS: the HODLR apply needs %u bytes of LDS", h.lds); return SMO_ERR_UNSUPPORTED; }
-        if (h.lds > 64u * 1024u) SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pois_apply_hodlr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds));
-        SMO_TRY(pool.alloc(&h.data, data.size()));
-        SMO_HIP(hipMemcpyAsync(h.data, data.data(), data.size() * sizeof(cd), hipMemcpyHostToDevice, stream));
-        SMO_HIP(hipStreamSynchronize(stream));
-        SMO_TRY(pool.upload(&h.rows, L.rows, stream)); SMO_TRY(pool.upload(&h.lut, L.lut, stream)); SMO_TRY(pool.upload(&h.tasks, L.tasks, stream));
+        if (!use_hodlr) return apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2);
+        ScopedTimer t(timing, k_apply, stream);
+        hop_launch(hA, stream, a, R3, nullptr, A3, nullptr, nullptr, a, Nz, L6 + 3 * nC, d_q);
         return SMO_OK;
     }
     dim3 pw_grid(size_t n) const { return dim3((unsigned)std::min<size_t>((n + 255) / 256, NPART)); }
@@ -641,6 +715,9 @@ public:
             for (int j = N - 1; j >= 1; j -= 2) q[j] = 1.0;
             if ((N - 1) % 2 == 0) q[0] = 0.5;
             SMO_TRY(pool.upload(&d_q, q, stream));
+            std::vector<double> qz(N, 0.0);
+            for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) qz[i] += Ti[(size_t)i * N + j] * q[j];
+            SMO_TRY(pool.upload(&d_qz, qz, stream));
         }
         // ---- x matrices (Hermitian half spectrum n = 0..a-1, rows/cols 2n = Re, 2n+1 = Im) --------------------------------------
         std::vector<double> Xi((size_t)Nx * 2 * a), XiD(Xi.size()), XiN(Xi.size()), Xf((size_t)2 * a * Nx), XfN(Xf.size()), XfNDa(Xf.size());
@@ -674,9 +751,7 @@ public:
         }
         // ---- tau operators, one per wavenumber, built by host threads ---------------------------------------------------------------------
         {
-            const char* mode = getenv("SMO_POIS_APPLY");
-            use_hodlr = !(mode && std::string(mode) == "dense");
-            if (mode && use_hodlr && std::string(mode) != "hodlr") { set_error("SMO_POIS_APPLY must be hodlr or dense, got %s", mode); return SMO_ERR_ARG; }
+            SMO_TRY(pois_apply_mode(&use_hodlr));
             const int n3 = 3 * N;
             const size_t sz = (size_t)(n3 + 3) * n3, szm = (size_t)2 * N * N;
             std::vector<cd> S, SH, SM((size_t)a * szm), SMH((size_t)a * szm);
@@ -684,7 +759,6 @@ public:
             const hodlr::Plan plan = hodlr::make_plan(n3);
             std::vector<hodlr::Factors> fac(use_hodlr ? a : 0);
             std::vector<std::vector<cd>> extras(use_hodlr ? a : 0);
-            const double rel_tol = getenv("SMO_POIS_HODLR_TOL") ? atof(getenv("SMO_POIS_HODLR_TOL")) : 1e-14;
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
             const int nthr = std::max(1, std::min<int>(std::min(a, 32), (int)std::thread::hardware_concurrency()));   // one wavenumber per task; <= 32 host threads
@@ -705,17 +779,7 @@ public:
                         for (int i = 0; i < n3 + 3; ++i) for (int j = 0; j < n3; ++j) SH[(size_t)n * sz + (size_t)j * (n3 + 3) + i] = std::conj(dst[(size_t)i * n3 + j]);
                         continue;
                     }
-                    // mode-major ordering (index 3*mode + variable) of rows and columns, then the HODLR factors (hodlr.hpp)
-                    perm.resize((size_t)n3 * n3);
-                    extras[n].resize((size_t)3 * n3);
-                    double mx = 0.0;
-                    for (int v = 0; v < 3; ++v) for (int j = 0; j < N; ++j) {
-                        const cd* row = dst + (size_t)(v * N + j) * n3;
-                        cd* prow = &perm[(size_t)(3 * j + v) * n3];
-                        for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) { prow[3 * i + w] = row[w * N + i]; mx = std::max(mx, std::abs(row[w * N + i])); }
-                    }
-                    for (int e = 0; e < 3; ++e) for (int w = 0; w < 3; ++w) for (int i = 0; i < N; ++i) extras[n][(size_t)e * n3 + 3 * i + w] = dst[(size_t)(n3 + e) * n3 + w * N + i];
-                    hodlr::factor(plan, perm.data(), n3, rel_tol * mx, fac[n]);
+                    hodlr_factor_reduced(plan, dst, N, perm, fac[n], extras[n]);
                 }
             };
             {
@@ -733,29 +797,12 @@ public:
             SMO_TRY(up(&d_SMN, SM)); SMO_TRY(up(&d_SMNH, SMH));
             if (!use_hodlr) {
                 SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SH, SH));
-                op_bytes = 0.5 * (double)(ada + a) * (double)sz * 16.0;
+                op_bytes = 0.5 * (double)(ada + a) * (double)sz * 16.0 * 7.0 / 9.0;     // 2/9 of either operator are the structural zeros pois_apply skips
             } else {
-                // one set of descriptors for all wavenumbers: every block gets the largest rank found for it
-                std::vector<int> K(plan.blocks.size(), 0), KH(plan.blocks.size(), 0);
-                for (int n = 0; n < a; ++n) for (size_t b = 0; b < K.size(); ++b) K[b] = std::max(K[b], fac[n].rank[b]);
-                for (size_t b = 0; b < K.size(); ++b) { KH[b] = K[plan.blocks[b].pair]; hodlr_max_rank = std::max(hodlr_max_rank, K[b]); }
-                // workgroups per wavenumber = tree nodes at this depth.  384 x 192 (MI355X): depth 1 52 us per launch, 2: 41, 3: 40, 4: 46 (the V^H
-                // rows of the blocks above the split are read by every task under them; below depth 3 there are too few workgroups)
-                const int split = getenv("SMO_POIS_HODLR_SPLIT") ? atoi(getenv("SMO_POIS_HODLR_SPLIT")) : 3;
-                if (split < 0 || split > 6) { set_error("SMO_POIS_HODLR_SPLIT must be in [0, 6]"); return SMO_ERR_ARG; }
-                const hodlr::Layout Lf = hodlr::make_layout(plan, K, split, 0, 3), La = hodlr::make_layout(plan, KH, split, 3, 0);
-                std::vector<cd> df((size_t)ada * Lf.stride), da((size_t)a * La.stride);
-                auto packer = [&](int t) {
-                    for (int n = t; n < a; n += nthr) {
-                        if (n < ada) hodlr::pack(plan, Lf, fac[n], extras[n].data(), false, &df[(size_t)n * Lf.stride]);
-                        hodlr::pack(plan, La, fac[n], extras[n].data(), true, &da[(size_t)n * La.stride]);
-                    }
-                };
-                std::vector<std::thread> th;
-                for (int t = 0; t < nthr; ++t) th.emplace_back(packer, t);
-                for (auto& t : th) t.join();
-                SMO_TRY(upload_hop(hF, Lf, df)); SMO_TRY(upload_hop(hA, La, da));
-                op_bytes = 0.5 * ((double)ada * Lf.stride + (double)a * La.stride) * 16.0;
+                double bf = 0.0, ba = 0.0;
+                SMO_TRY(hop_build(pool, stream, plan, fac, extras, ada, false, nthr, hF, &bf));
+                SMO_TRY(hop_build(pool, stream, plan, fac, extras, a, true, nthr, hA, &ba));
+                op_bytes = 0.5 * (bf + ba);
             }
         }
         // ---- work buffers -----------------------------------------------------------------------------------------------
@@ -775,14 +822,22 @@ public:
         SMO_TRY(make_phase(F0x, M2a, Nz, Nx, {{A_Xf_DA, g_(GR, 0), c_(H, 0)}, {A_Xf_DA, g_(GR, 1), c_(H, 1)}}));
         SMO_TRY(make_phase(F0z, M2a, Nz, Nz, {{c_(H, 0), B_ZfT_DA, c_(S6, 0)}, {c_(H, 1), B_ZfT_DA, c_(S6, 1)}}));
         SMO_TRY(make_phase(F0d, M2a, Nz, Nz, {{c_(S6, 0), B_DzT, c_(S6, 3)}, {c_(S6, 1), B_DzT, c_(S6, 4)}}));
-        { std::vector<GemmDesc> v, w; for (int f = 0; f < 3; ++f) { v.push_back({c_(S6, f), B_DzT, c_(S6, 3 + f)}); w.push_back({c_(L6, 3 + f), B_Dz, c_(HC, f)}); }
-          SMO_TRY(make_phase(F1d, M2a, Nz, Nz, v)); SMO_TRY(make_phase(Ad, M2a, Nz, Nz, w)); }
-        // forward step
-        { std::vector<GemmDesc> v; for (int f = 0; f < 6; ++f) v.push_back({c_(S6, f), B_ZiT, c_(G1, f)}); SMO_TRY(make_phase(Fz, M2a, Nz, Nz, v)); }
+        // adjoint step, first phase: R3 = lambda_{u,v,rho} + lambda_{uz,vz,rhoz} Dz (the sum is the product's epilogue)
+        { std::vector<GemmDesc> w; for (int f = 0; f < 3; ++f) w.push_back({c_(L6, 3 + f), B_Dz, c_(R3, f), c_(L6, f), 1.0});
+          SMO_TRY(make_phase(Ad, M2a, Nz, Nz, w)); }
+        // forward step.  Lines in z of [u, v, rho, uz, vz, rhoz]: the derivative variables of the tau system are  uz = u Dz^T + (uz)_{N-1} q  (see
+        // pois_rank1_add), so their lines come straight from u, v, rho and the three scalars per wavenumber the operator apply returns:
+        //   uz Ti^T = u (Ti Dz)^T + x (x) (Ti q)      — Fz1; the first step (Fz) takes the derivative coefficients of the initial state as given
+        { std::vector<GemmDesc> v, v1;
+          for (int f = 0; f < 6; ++f) v.push_back({c_(S6, f), B_ZiT, c_(G1, f)});
+          for (int f = 0; f < 3; ++f) v1.push_back({c_(S6, f), B_ZiT, c_(G1, f)});
+          for (int f = 0; f < 3; ++f) v1.push_back({c_(S6, f), B_DZiT, c_(G1, 3 + f), nullptr, 0.0, d_X3 + f, d_qz});
+          SMO_TRY(make_phase(Fz, M2a, Nz, Nz, v)); SMO_TRY(make_phase(Fz1, M2a, Nz, Nz, v1)); }
         SMO_TRY(make_phase(Fx, Nx, Nz, M2a, {{A_Xi, c_(G1, 0), g_(GR, 0)}, {A_XiD, c_(G1, 0), g_(GR, 1)}, {A_Xi, c_(G1, 3), g_(GR, 2)},
                                              {A_Xi, c_(G1, 1), g_(GR, 3)}, {A_XiD, c_(G1, 1), g_(GR, 4)}, {A_Xi, c_(G1, 4), g_(GR, 5)},
                                              {A_XiD, c_(G1, 2), g_(GR, 6)}, {A_Xi, c_(G1, 5), g_(GR, 7)}}));
-        { std::vector<GemmDesc> v, w; for (int f = 0; f < 3; ++f) { v.push_back({A_Xf_DA, g_(PR, f), c_(H, f)}); w.push_back({c_(H, f), B_ZfT_DA, c_(HC, f)}); }
+        // right-hand side of the step: R3 = state / dt + transformed products (the sum is the product's epilogue)
+        { std::vector<GemmDesc> v, w; for (int f = 0; f < 3; ++f) { v.push_back({A_Xf_DA, g_(PR, f), c_(H, f)}); w.push_back({c_(H, f), B_ZfT_DA, c_(R3, f), c_(S6, f), 1.0 / cfg.dt}); }
           SMO_TRY(make_phase(Fxf, M2a, Nz, Nx, v)); SMO_TRY(make_phase(Fzf, M2a, Nz, Nz, w)); }
         // mix-norm fields psi (cur3[2]) and psiz (cur3[1]) -> grids gx = dx psi, gz = psiz
         SMO_TRY(make_phase(M1z, M2a, Nz, Nz, {{c_(cur3, 2), B_ZiT, c_(G1, 0)}, {c_(cur3, 1), B_ZiT, c_(G1, 1)}}));
@@ -797,8 +852,8 @@ public:
         // adjoint step
         { std::vector<GemmDesc> v;
           for (int f = 0; f < 3; ++f) v.push_back({c_(A3, f), B_Zf_DA, c_(G1, f)});
-          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_ZiT, c_(G1, 3 + f)});
-          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_DZiT, c_(G1, 6 + f)});
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_ZiT, c_(G1, 3 + f), nullptr, 0.0, nullptr, nullptr, 1});     // dyn: the launch points these at the
+          for (int f = 0; f < 3; ++f) v.push_back({c_(cur3, f), B_DZiT, c_(G1, 6 + f), nullptr, 0.0, nullptr, nullptr, 1});    // step's snapshot (run(Az, -1, shift))
           SMO_TRY(make_phase(Az, M2a, Nz, Nz, v)); }
         SMO_TRY(make_phase(Ax, Nx, Nz, M2a, {{A_XiN_DA, c_(G1, 0), g_(GR, 0)}, {A_XiN_DA, c_(G1, 1), g_(GR, 1)}, {A_XiN_DA, c_(G1, 2), g_(GR, 2)},
                                              {A_Xi, c_(G1, 3), g_(GR, 3)}, {A_Xi, c_(G1, 4), g_(GR, 4)}, {A_XiD, c_(G1, 3), g_(GR, 5)},
@@ -824,7 +879,7 @@ public:
         for (int r = 0; r < nrows; ++r) { double s = 0.0; for (int i = 0; i < NPART; ++i) s += h_part[(size_t)r * NPART + i]; out[r] = s; }
         return SMO_OK;
     }
-    int state_grids() { SMO_TRY(run(Fz)); return run(Fx); }
+    int state_grids(bool initial) { SMO_TRY(run(initial ? Fz : Fz1)); return run(Fx); }
     int nl_and_energy(int step) {
         ScopedTimer t(timing, k_point, stream);
         hipLaunchKernelGGL(pois_nl, dim3(NPART), dim3(256), 0, stream, GR, PR, d_Wz, d_part + (size_t)step * NPART, nG, Nz);
@@ -842,19 +897,10 @@ public:
         SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_rz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemcpyAsync(snap(0), S6, 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         for (int n = 0; n < N; ++n) {
-            SMO_TRY(state_grids());
+            SMO_TRY(state_grids(n == 0));
             SMO_TRY(nl_and_energy(n));
-            SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));
-            {
-                ScopedTimer t(timing, k_point, stream);
-                hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, S6, 1.0 / cfg.dt, HC, 3 * nC);
-            }
-            SMO_TRY(solve_fwd(n));
-            SMO_TRY(run(F1d));                                               // uz, vz, rhoz = (u, v, rho) Dz^T + last coefficient * q
-            {
-                ScopedTimer t(timing, k_point, stream);
-                hipLaunchKernelGGL(pois_rank1_add, pw_grid(3 * nC), dim3(256), 0, stream, S6 + 3 * nC, d_X3, d_q, 2 * a, Nz);
-            }
+            SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));                           // R3 = state / dt + transformed products
+            SMO_TRY(solve_fwd(n));                                           // u, v, rho and the last coefficient of uz, vz, rhoz (d_X3)
         }
         double cost = 0.0;
         if (s_cost == 1) {
@@ -877,7 +923,7 @@ public:
             SMO_TRY(sum_partials(N + 1, 1, &e));
             cost = 0.5 * e / V;
         } else {
-            SMO_TRY(state_grids());
+            SMO_TRY(state_grids(N == 0));
             SMO_TRY(nl_and_energy(N));
             std::vector<double> e(N + 1);
             SMO_TRY(sum_partials(0, N + 1, e.data()));
@@ -922,14 +968,12 @@ public:
         for (int idx = N - 1; idx >= 0; --idx) {
             // S^H lambda with the reduced operator: lambda_{u,v,rho} + lambda_{uz,vz,rhoz} Dz, and the three scalars q . lambda_z
             SMO_TRY(run(Ad));
-            {
+            if (!use_hodlr) {                                                // (the HODLR apply forms the three scalars while it stages its input)
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
-                hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, L6, 1.0, HC, 3 * nC);
             }
             SMO_TRY(solve_adj());
-            SMO_HIP(hipMemcpyAsync(cur3, snap(idx), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            SMO_TRY(run(Az)); SMO_TRY(run(Ax));
+            SMO_TRY(run(Az, -1, ((long long)(intptr_t)snap(idx) - (long long)(intptr_t)cur3) / (long long)sizeof(double))); SMO_TRY(run(Ax));      // the forward state's lines straight from snapshot idx
             {
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_adj_products, pw_grid(nG), dim3(256), 0, stream, GR, PR, d_Wz, -cfg.dt / V, forcing ? 1 : 0, nG, Nz);
@@ -1061,6 +1105,9 @@ public:
     double *B_ZiT = nullptr, *B_DZiT = nullptr, *B_ZfT = nullptr, *B_DzT = nullptr, *A_Xi = nullptr, *A_XiD = nullptr, *A_Xf = nullptr;
     double *d_Wq = nullptr, *d_b0 = nullptr, *d_bz0 = nullptr, *d_q = nullptr, *d_X3 = nullptr;
     double2 *d_S = nullptr, *d_SA = nullptr, *d_SMN = nullptr;
+    HOp hS, hSA;                                           // the forward and the adjoint IVP's operators in HODLR form (the default)
+    bool use_hodlr = true;
+    double op_bytes = 0.0;
     double *S6 = nullptr, *A6 = nullptr, *R3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr, *HC = nullptr,
            *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
@@ -1156,8 +1203,13 @@ public:
             SMO_TRY(pool.upload(&d_b0, b0, stream)); SMO_TRY(pool.upload(&d_bz0, bz0, stream));
         }
         {
+            SMO_TRY(pois_apply_mode(&use_hodlr));
             const size_t sz = (size_t)(3 * N + 3) * 3 * N, szm = (size_t)2 * N * N;
-            std::vector<cd> S((size_t)a * sz), SA((size_t)a * sz), SM((size_t)a * szm);
+            std::vector<cd> S, SA, SM((size_t)a * szm);
+            if (!use_hodlr) { S.resize((size_t)a * sz); SA.resize((size_t)a * sz); }
+            const hodlr::Plan plan = hodlr::make_plan(3 * N);
+            std::vector<hodlr::Factors> fS(use_hodlr ? a : 0), fA(use_hodlr ? a : 0);
+            std::vector<std::vector<cd>> eS(use_hodlr ? a : 0), eA(use_hodlr ? a : 0);
             std::vector<int> rc(a, SMO_OK);
             std::vector<std::string> msg(a);
             const int nthr = std::max(1, std::min<int>(std::min(a, 32), (int)std::thread::hardware_concurrency()));   // one wavenumber per task; <= 32 host threads
@@ -1166,13 +1218,19 @@ public:
                 for (int f = 0; f < 3; ++f) std::copy(&s[((size_t)(3 + f) * N + N - 1) * 3 * N], &s[((size_t)(3 + f) * N + N - 1) * 3 * N] + 3 * N, dst + (size_t)(3 * N + f) * 3 * N);
             };
             auto work = [&](int t) {
+                std::vector<cd> red(use_hodlr ? sz : 0), perm;
                 for (int n = t; n < a; n += nthr) {
                     std::vector<cd> s, sa, sm;
                     int r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, s, false);
                     if (r == SMO_OK) r = build_solve_map(ch, n, k1 * n, 1.0 / cfg.dt, Re, Pe, Ri, sa, true);
                     if (r == SMO_OK) r = build_mixnorm_map(ch, n, k1 * n, sm);
                     if (r != SMO_OK) { rc[n] = r; msg[n] = last_error(); continue; }
-                    reduce(s, &S[(size_t)n * sz]); reduce(sa, &SA[(size_t)n * sz]);
+                    if (use_hodlr) {
+                        reduce(s, red.data());  hodlr_factor_reduced(plan, red.data(), N, perm, fS[n], eS[n]);
+                        reduce(sa, red.data()); hodlr_factor_reduced(plan, red.data(), N, perm, fA[n], eA[n]);
+                    } else {
+                        reduce(s, &S[(size_t)n * sz]); reduce(sa, &SA[(size_t)n * sz]);
+                    }
                     std::copy(sm.begin(), sm.end(), SM.begin() + (size_t)n * szm);
                 }
             };
@@ -1186,7 +1244,16 @@ public:
                 SMO_HIP(hipStreamSynchronize(stream));
                 return SMO_OK;
             };
-            SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SA, SA)); SMO_TRY(up(&d_SMN, SM));
+            SMO_TRY(up(&d_SMN, SM));
+            if (use_hodlr) {
+                double b1 = 0.0, b2 = 0.0;
+                SMO_TRY(hop_build(pool, stream, plan, fS, eS, a, false, nthr, hS, &b1));
+                SMO_TRY(hop_build(pool, stream, plan, fA, eA, a, false, nthr, hSA, &b2));
+                op_bytes = 0.5 * (b1 + b2);
+            } else {
+                SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SA, SA));
+                op_bytes = (double)a * (double)sz * 16.0;
+            }
         }
         SMO_TRY(pool.alloc(&S6, 6 * nC)); SMO_TRY(pool.alloc(&A6, 6 * nC)); SMO_TRY(pool.alloc(&R3, 3 * nC)); SMO_TRY(pool.alloc(&cur3, 3 * nC));
         SMO_TRY(pool.alloc(&G1, 12 * nL)); SMO_TRY(pool.alloc(&GR, 17 * nG)); SMO_TRY(pool.alloc(&PR, 3 * nG)); SMO_TRY(pool.alloc(&H, 3 * nL));
@@ -1227,7 +1294,7 @@ public:
         SMO_TRY(make_phase(Gz2, M2a, Gz, Nz, {{c_(A6, 0), B_ZiT, l_(G1, 0)}, {c_(A6, 1), B_ZiT, l_(G1, 1)}}));
         SMO_TRY(make_phase(Gx2, Gx, Gz, M2a, {{A_Xi, l_(G1, 0), g_(GR, 0)}, {A_Xi, l_(G1, 1), g_(GR, 1)}}));
         k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
-        k_apply = timing.add_class("pois_apply (tau operator, batched complex GEMV)", (double)a * (3 * N + 3) * 3 * N * 16.0);
+        k_apply = timing.add_class(use_hodlr ? "pois_apply_hodlr (tau operator, HODLR form)" : "pois_apply (tau operator, batched complex GEMV)", op_bytes, op_bytes);
         k_point = timing.add_class("pois pointwise", 0.0);
         return SMO_OK;
     }
@@ -1239,13 +1306,18 @@ public:
         return SMO_OK;
     }
     // one SBDF1 step of a 6-field state with the operator S: rhs grids PR[0..2] -> state (u, w, b, uz, wz, bz)
-    int advance(double* state, const double2* S, const Phase& deriv) {
+    int advance(double* state, bool adjoint_ivp, const Phase& deriv) {
         SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));
         {
             ScopedTimer t(timing, k_point, stream);
             hipLaunchKernelGGL(pois_axpy, pw_grid(3 * nC), dim3(256), 0, stream, R3, state, 1.0 / cfg.dt, HC, 3 * nC);
         }
-        SMO_TRY(apply(S, R3, state, d_X3, 3, 3, 3));
+        if (use_hodlr) {
+            ScopedTimer t(timing, k_apply, stream);
+            hop_launch(adjoint_ivp ? hSA : hS, stream, a, R3, nullptr, state, d_X3, nullptr, a, Nz);
+        } else {
+            SMO_TRY(apply(adjoint_ivp ? d_SA : d_S, R3, state, d_X3, 3, 3, 3));
+        }
         SMO_TRY(run(deriv));
         ScopedTimer t(timing, k_point, stream);
         hipLaunchKernelGGL(pois_rank1_add, pw_grid(3 * nC), dim3(256), 0, stream, state + 3 * nC, d_X3, d_q, 2 * a, Nz);
@@ -1273,7 +1345,7 @@ public:
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_nl, dim3(NPART), dim3(256), 0, stream, GR, PR, d_Wq, d_part + (size_t)n * NPART, nG, Gz);
             }
-            SMO_TRY(advance(S6, d_S, F1d));
+            SMO_TRY(advance(S6, false, F1d));
         }
         double cost = 0.0;
         if (s_cost == 1) {
@@ -1316,7 +1388,7 @@ public:
                 ScopedTimer t(timing, k_point, stream);
                 hipLaunchKernelGGL(pois_cnts_adj_rhs, pw_grid(nG), dim3(256), 0, stream, GR, PR, s_cost == 0 ? 1 : 0, nG);
             }
-            SMO_TRY(advance(A6, d_SA, A1d));
+            SMO_TRY(advance(A6, true, A1d));
         }
         SMO_TRY(run(Gz2)); SMO_TRY(run(Gx2));
         SMO_HIP(hipMemcpyAsync(grad[0], GR, 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));

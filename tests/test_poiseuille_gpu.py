@@ -183,3 +183,23 @@ def test_apply_mode_knob_is_validated(monkeypatch):
     with pytest.raises(Exception):
         dom.context(500., 0.05, 2, 5e-3, 0, 1., 0.125)
     dom.drop_contexts()
+
+
+@pytest.mark.parametrize("Nx,Nz,n,s", [(32, 24, 6, 0), (64, 32, 5, 1), (256, 128, 6, 1)])
+def test_continuous_hodlr_apply_matches_dense_apply(Nx, Nz, n, s, monkeypatch):
+    """Continuous formulation: both IVP operators (forward and adjoint) in HODLR form against the dense stream."""
+    from oracle.poiseuille import PoiseuilleCntsOracle, synthetic_ic_cnts
+    X = synthetic_ic_cnts(PoiseuilleCntsOracle(Nx, Nz, dt=5e-3, N_ITERS=1, s=s, delta=0.3), 5)
+    res = {}
+    for mode in ("dense", "hodlr"):
+        monkeypatch.setenv("SMO_POIS_APPLY", mode)
+        dom = pz.PoiseuilleDomain(Nx, Nz, continuous=True)
+        buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+        args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.3]
+        J = pz.FWD_Solve_Cnts([X], *args)
+        g = pz.ADJ_Solve_Cnts([X], *args)[0]
+        res[mode] = (J, g, buf['b_fwd'][:, :, -1].copy())
+        dom.drop_contexts()
+    (Jd, gd, bd), (Jh, gh, bh) = res["dense"], res["hodlr"]
+    assert abs(Jh - Jd) <= 1e-11 * abs(Jd), (Jh, Jd)
+    assert rel(gh, gd) < 1e-11 and rel(bh, bd) < 1e-11, (rel(gh, gd), rel(bh, bd))

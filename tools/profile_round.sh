@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the benchmark command itself (per-kernel average durations to set against bench.py's HIP events)
 #   2. HBM traffic counters, separate --pmc passes (FETCH_SIZE | WRITE_SIZE), of a short KDyn run at 128^3 and 256^3
 #      -> pmc_<N>.json stamped with the sha of the kernel sources (bench.py quotes `traffic` only from a summary of the same sources)
-#   3. kernel statistics of the Poiseuille path
+#   3. kernel statistics and HBM traffic counters of the Poiseuille path
 # usage: tools/profile_round.sh [bench steps]
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -21,10 +21,13 @@ for N in 128 256; do
   echo "pmc $N done"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pois_stats -o pois -- python3 $R/tools/prof_pois.py 384 192 200 1 > $OUT/pois_under_rocprof.json 2> $OUT/pois_under_rocprof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pois/fetch -o f -- python3 $R/tools/prof_pois.py 384 192 40 1 > $OUT/pmc_pois_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pois/write -o w -- python3 $R/tools/prof_pois.py 384 192 40 1 > $OUT/pmc_pois_write.log 2>&1
 echo "pois done"
 cd $R
 for N in 128 256; do
   python3 tools/summarize_pmc.py $OUT/pmc_${N} > $OUT/pmc_${N}_summary.txt
   python3 tools/pmc_to_json.py $OUT/pmc_${N} $OUT/pmc_${N}.json $N || true
 done
+python3 tools/summarize_pmc.py $OUT/pmc_pois > $OUT/pmc_pois_summary.txt
 find $OUT -name "*kernel_stats.csv"
