@@ -614,8 +614,8 @@ public:
     double *S6 = nullptr, *R3 = nullptr, *L6 = nullptr, *A3 = nullptr, *cur3 = nullptr, *G1 = nullptr, *GR = nullptr, *PR = nullptr, *H = nullptr,
            *HC = nullptr, *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
-    int k_gemm = -1, k_apply = -1, k_point = -1;
-    double op_bytes = 0.0;
+    int k_gemm = -1, k_apply = -1, k_apply_adj = -1, k_point = -1;
+    double op_bytes = 0.0, op_bytes_adj = 0.0;
 
     struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
     Phase F0x, F0z, F0d, Fz1, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
@@ -634,7 +634,7 @@ public:
     int apply(const double2* S, const double* in, const double* xin_v, double* out, double* xout_v, double* snap, int nin, int xin, int nout,
               int xout, int modes, int structure = 0) {
         const int rows = nout * Nz + xout, cols = nin * Nz + xin;
-        ScopedTimer t(timing, k_apply, stream);
+        ScopedTimer t(timing, structure == 2 ? k_apply_adj : k_apply, stream);
         hipLaunchKernelGGL(pois_apply, dim3((unsigned)(modes * ((rows + APPLY_ROWS - 1) / APPLY_ROWS))), dim3(256), cols * sizeof(double2), stream, S, in, xin_v, out, xout_v,
                            snap, a, modes, Nz, nin, xin, nout, xout, structure);
         return SMO_OK;
@@ -650,7 +650,7 @@ public:
     }
     int solve_adj() {
         if (!use_hodlr) return apply(d_SH, R3, d_X3, A3, nullptr, nullptr, 3, 3, 3, 0, a, 2);
-        ScopedTimer t(timing, k_apply, stream);
+        ScopedTimer t(timing, k_apply_adj, stream);
         hop_launch(hA, stream, a, R3, nullptr, A3, nullptr, nullptr, a, Nz, L6 + 3 * nC, d_q);
         return SMO_OK;
     }
@@ -797,12 +797,11 @@ public:
             SMO_TRY(up(&d_SMN, SM)); SMO_TRY(up(&d_SMNH, SMH));
             if (!use_hodlr) {
                 SMO_TRY(up(&d_S, S)); SMO_TRY(up(&d_SH, SH));
-                op_bytes = 0.5 * (double)(ada + a) * (double)sz * 16.0 * 7.0 / 9.0;     // 2/9 of either operator are the structural zeros pois_apply skips
+                op_bytes = (double)ada * (double)sz * 16.0 * 7.0 / 9.0;                 // 2/9 of either operator are the structural zeros pois_apply skips
+                op_bytes_adj = (double)a * (double)sz * 16.0 * 7.0 / 9.0;
             } else {
-                double bf = 0.0, ba = 0.0;
-                SMO_TRY(hop_build(pool, stream, plan, fac, extras, ada, false, nthr, hF, &bf));
-                SMO_TRY(hop_build(pool, stream, plan, fac, extras, a, true, nthr, hA, &ba));
-                op_bytes = 0.5 * (bf + ba);
+                SMO_TRY(hop_build(pool, stream, plan, fac, extras, ada, false, nthr, hF, &op_bytes));
+                SMO_TRY(hop_build(pool, stream, plan, fac, extras, a, true, nthr, hA, &op_bytes_adj));
             }
         }
         // ---- work buffers -----------------------------------------------------------------------------------------------
@@ -867,8 +866,9 @@ public:
         SMO_TRY(make_phase(Gz, M2a, Nz, Nz, {{c_(L6, 0), B_Zf, c_(G1, 0)}, {c_(L6, 1), B_Zf, c_(G1, 1)}}));
         SMO_TRY(make_phase(Gx, Nx, Nz, M2a, {{A_XiN, c_(G1, 0), g_(GR, 0)}, {A_XiN, c_(G1, 1), g_(GR, 1)}}));
         k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
-        // bytes of the operators one launch streams: the mean of the forward (de-aliased wavenumbers) and the transposed apply (all of them)
+        // bytes = the operators one launch streams: the forward apply runs over the de-aliased wavenumbers, the transposed one over all of them
         k_apply = timing.add_class(use_hodlr ? "pois_apply_hodlr (tau operator, HODLR form)" : "pois_apply (tau operator, batched complex GEMV)", op_bytes, op_bytes);
+        k_apply_adj = timing.add_class(use_hodlr ? "pois_apply_hodlr (transposed tau operator)" : "pois_apply (transposed tau operator)", op_bytes_adj, op_bytes_adj);
         k_point = timing.add_class("pois pointwise", 0.0);
         return SMO_OK;
     }
@@ -886,6 +886,44 @@ public:
         return SMO_OK;
     }
 
+    // the two time loops: nothing but kernel launches on fixed buffers.  (Replaying each as one captured HIP graph was measured in round 2:
+    // 324.9 against 325.1 ms per gradient — the ~7 us between two dependent launches of 5-45 us are GPU-side, not host time; not kept.)
+    int fwd_loop() {
+        const int N = cfg.n_iters;
+        for (int n = 0; n < N; ++n) {
+            SMO_TRY(state_grids(n == 0));
+            SMO_TRY(nl_and_energy(n));
+            SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));                           // R3 = state / dt + transformed products
+            SMO_TRY(solve_fwd(n));                                           // u, v, rho and the last coefficient of uz, vz, rhoz (d_X3)
+        }
+        return SMO_OK;
+    }
+    int adj_loop() {
+        const int N = cfg.n_iters;
+        const bool forcing = s_cost == 0;
+        for (int idx = N - 1; idx >= 0; --idx) {
+            // S^H lambda with the reduced operator: lambda_{u,v,rho} + lambda_{uz,vz,rhoz} Dz, and the three scalars q . lambda_z
+            SMO_TRY(run(Ad));
+            if (!use_hodlr) {                                                // (the HODLR apply forms the three scalars while it stages its input)
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
+            }
+            SMO_TRY(solve_adj());
+            SMO_TRY(run(Az, -1, ((long long)(intptr_t)snap(idx) - (long long)(intptr_t)cur3) / (long long)sizeof(double))); SMO_TRY(run(Ax));      // the forward state's lines straight from snapshot idx
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_adj_products, pw_grid(nG), dim3(256), 0, stream, GR, PR, d_Wz, -cfg.dt / V, forcing ? 1 : 0, nG, Nz);
+            }
+            const int np = forcing ? 10 : 8;
+            SMO_TRY(run(Axf, np)); SMO_TRY(run(Azf, np));
+            {
+                ScopedTimer t(timing, k_point, stream);
+                hipLaunchKernelGGL(pois_adj_combine, pw_grid(nC), dim3(256), 0, stream, L6, A3, HC, 1.0 / cfg.dt, forcing ? 1 : 0, nC);
+            }
+        }
+        return SMO_OK;
+    }
+
     int forward_dev(const double* const* X, double* J) override {
         have_forward = false;
         const int N = cfg.n_iters;
@@ -896,12 +934,7 @@ public:
         SMO_HIP(hipMemcpyAsync(S6 + 2 * nC, d_rho0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_rz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemcpyAsync(snap(0), S6, 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        for (int n = 0; n < N; ++n) {
-            SMO_TRY(state_grids(n == 0));
-            SMO_TRY(nl_and_energy(n));
-            SMO_TRY(run(Fxf)); SMO_TRY(run(Fzf));                           // R3 = state / dt + transformed products
-            SMO_TRY(solve_fwd(n));                                           // u, v, rho and the last coefficient of uz, vz, rhoz (d_X3)
-        }
+        SMO_TRY(fwd_loop());
         double cost = 0.0;
         if (s_cost == 1) {
             // mix-norm (POIS:1053-1124): (psi, psiz) = S^MN rho_N; snapshot N holds (dx psi, psiz, psi); cost = <grad psi, grad psi> / 2
@@ -941,7 +974,6 @@ public:
     int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
         if (adjoint_type != SMO_ADJ_DISCRETE) { set_error("POIS: only the Discrete formulation is built"); return SMO_ERR_UNSUPPORTED; }
         const int N = cfg.n_iters;
-        const bool forcing = s_cost == 0;
         SMO_HIP(hipMemsetAsync(L6, 0, 6 * nC * sizeof(double), stream));
         SMO_HIP(hipMemcpyAsync(cur3, snap(N), 3 * nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         if (s_cost == 1) {
@@ -965,26 +997,7 @@ public:
             }
             SMO_TRY(run(T0xf)); SMO_TRY(run(T0zf));
         }
-        for (int idx = N - 1; idx >= 0; --idx) {
-            // S^H lambda with the reduced operator: lambda_{u,v,rho} + lambda_{uz,vz,rhoz} Dz, and the three scalars q . lambda_z
-            SMO_TRY(run(Ad));
-            if (!use_hodlr) {                                                // (the HODLR apply forms the three scalars while it stages its input)
-                ScopedTimer t(timing, k_point, stream);
-                hipLaunchKernelGGL(pois_rank1_dot, dim3((unsigned)((3LL * 2 * a + 3) / 4)), dim3(256), 0, stream, d_X3, L6 + 3 * nC, d_q, 2 * a, Nz);
-            }
-            SMO_TRY(solve_adj());
-            SMO_TRY(run(Az, -1, ((long long)(intptr_t)snap(idx) - (long long)(intptr_t)cur3) / (long long)sizeof(double))); SMO_TRY(run(Ax));      // the forward state's lines straight from snapshot idx
-            {
-                ScopedTimer t(timing, k_point, stream);
-                hipLaunchKernelGGL(pois_adj_products, pw_grid(nG), dim3(256), 0, stream, GR, PR, d_Wz, -cfg.dt / V, forcing ? 1 : 0, nG, Nz);
-            }
-            const int np = forcing ? 10 : 8;
-            SMO_TRY(run(Axf, np)); SMO_TRY(run(Azf, np));
-            {
-                ScopedTimer t(timing, k_point, stream);
-                hipLaunchKernelGGL(pois_adj_combine, pw_grid(nC), dim3(256), 0, stream, L6, A3, HC, 1.0 / cfg.dt, forcing ? 1 : 0, nC);
-            }
-        }
+        SMO_TRY(adj_loop());
         SMO_TRY(run(Gd));
         {
             ScopedTimer t(timing, k_point, stream);
