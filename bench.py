@@ -18,14 +18,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+KDYN_SOURCES = ("kdyn.hip", "fft_lds.hpp", "comm.hpp", "smo_common.hpp")     # the translation unit the KDyn kernels are compiled from
+
+
 def source_sha():
-    """sha256 over the kernel sources of libsmo (sorted names + contents): the identity a PMC summary must carry to be quoted."""
-    import glob
+    """sha256 over the sources of the KDyn kernels (kdyn.hip and the headers it includes; names + contents): the identity a PMC summary
+    must carry for bench.py to quote its traffic figures."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "spheremanopt_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    for f in KDYN_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

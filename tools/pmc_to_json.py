@@ -33,13 +33,13 @@ def classify(name):
 
 
 def source_sha():
-    """Identity of the kernel sources the counters were collected from (same function as bench.py's): bench.py quotes `traffic` only
-    from a summary whose source_sha equals the one of the tree it runs in."""
+    """Identity of the kernel sources the counters were collected from (same function as bench.py's: kdyn.hip and the headers it includes):
+    bench.py quotes `traffic` only from a summary whose source_sha equals the one of the tree it runs in."""
     import hashlib
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "spheremanopt_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    for f in ("kdyn.hip", "fft_lds.hpp", "comm.hpp", "smo_common.hpp"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
