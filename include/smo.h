@@ -62,7 +62,8 @@ typedef struct smo_config {
     int    kind;        /* SMO_SH23 | SMO_SHB23 | SMO_KDYN | SMO_POIS */
     int    npts;        /* Npts as the reference's Generate_IC receives it (SH23 256, SHB23 512, KDYN 128).  Transform lengths are compile-time
                            instantiations with factors 2, 3, 5 — SH23: 2^k, 3*2^k, 5*2^k, 15*2^k in [16, 1024]; SHB23: 2^k, 3*2^k in [64, 1024];
-                           KDYN: 8, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320; anything else: SMO_ERR_UNSUPPORTED */
+                           KDYN: 8, 12, 16, 20, 24, 32, 36, 40, 48, 60, 64, 72, 80, 96, 100, 120, 128, 144, 160, 192, 200, 240, 256, 320;
+                           anything else: SMO_ERR_UNSUPPORTED */
     double x0, x1;      /* interval of every axis: SH23 (0,12pi), SHB23 (-20,20), KDYN (0,2pi) */
     double dt;          /* time step */
     int    n_iters;     /* N_ITERS (the forward solve executes N_ITERS+1 steps for SH23/KDYN, like the reference) */

@@ -829,10 +829,10 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        static const int sizes[] = {8, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320};
+        static const int sizes[] = {8, 12, 16, 20, 24, 32, 36, 40, 48, 60, 64, 72, 80, 96, 100, 120, 128, 144, 160, 192, 200, 240, 256, 320};
         if (std::find(std::begin(sizes), std::end(sizes), N) == std::end(sizes)) {
             // the transform lengths G = 3N/2 are compile-time instantiations (factors 2, 3 and 5); the reference, through FFTW, takes any even Npts
-            set_error("KDYN: npts must be one of 8,16,20,24,32,40,48,64,80,96,128,160,192,256,320 (got %d)", N);
+            set_error("KDYN: npts must be one of 8,12,16,20,24,32,36,40,48,60,64,72,80,96,100,120,128,144,160,192,200,240,256,320 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
         if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
@@ -942,6 +942,15 @@ public:
             case 120: return f(std::integral_constant<int, 120>());
             case 240: return f(std::integral_constant<int, 240>());
             case 480: return f(std::integral_constant<int, 480>());
+            case 90: return f(std::integral_constant<int, 90>());      // Npts = 60, 120, 240 and 100, 200: factors 3 and 5 together, 5 twice
+            case 180: return f(std::integral_constant<int, 180>());
+            case 360: return f(std::integral_constant<int, 360>());
+            case 150: return f(std::integral_constant<int, 150>());
+            case 300: return f(std::integral_constant<int, 300>());
+            case 18: return f(std::integral_constant<int, 18>());      // Npts = 12, 36, 72, 144: 3 more than once
+            case 54: return f(std::integral_constant<int, 54>());
+            case 108: return f(std::integral_constant<int, 108>());
+            case 216: return f(std::integral_constant<int, 216>());
             case 36: return f(std::integral_constant<int, 36>());      // Npts = 24, the reference script's default
             case 72: return f(std::integral_constant<int, 72>());
             case 144: return f(std::integral_constant<int, 144>());
