@@ -253,7 +253,7 @@ inline void pack(const Plan& p, const Layout& L, const Factors& f, const cd* ext
     const int n = p.n;
     for (size_t b = 0; b < p.blocks.size(); ++b) {
         const Block& B = p.blocks[b];
-        const int nc = B.c1 - B.c0, m = B.r1 - B.r0;
+        const int nc = B.c1 - B.c0;
         const uint32_t lenp = pad8(nc);
         if (!adjoint) {
             const int k = f.rank[b];
@@ -262,7 +262,6 @@ inline void pack(const Plan& p, const Layout& L, const Factors& f, const cd* ext
             const int pb = B.pair, k = f.rank[pb];
             for (int i = 0; i < k; ++i) for (int c = 0; c < nc; ++c) dst[L.vh_off[b] + (size_t)i * lenp + c] = std::conj(f.U[pb][(size_t)c * k + i]);
         }
-        (void)m;
     }
     for (size_t l = 0; l < p.leaves.size(); ++l) {
         const Node& N = p.nodes[p.leaves[l]];
