@@ -203,3 +203,31 @@ def test_continuous_hodlr_apply_matches_dense_apply(Nx, Nz, n, s, monkeypatch):
     (Jd, gd, bd), (Jh, gh, bh) = res["dense"], res["hodlr"]
     assert abs(Jh - Jd) <= 1e-11 * abs(Jd), (Jh, Jd)
     assert rel(gh, gd) < 1e-11 and rel(bh, bd) < 1e-11, (rel(gh, gd), rel(bh, bd))
+
+
+def test_reference_resolution_full_length_fixture():
+    """The workload of bench.py's Poiseuille line — 384 x 192, 1000 steps (T = 5), mix-norm cost, the same seeded input — against the oracle
+    run committed as tests/golden/oracle_poiseuille_384x192_n1000_s1.npz (tools/gen_golden_poiseuille_full.py): the HODLR operators, the
+    fused epilogues and the in-place snapshot reads at the size and length that is timed."""
+    path = os.path.join(GOLDEN, "oracle_poiseuille_384x192_n1000_s1.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/oracle_poiseuille_384x192_n1000_s1.npz not generated (tools/gen_golden_poiseuille_full.py)")
+    gold = np.load(path)
+    Nx, Nz, n, s = int(gold["Nx"]), int(gold["Nz"]), int(gold["steps"]), int(gold["s"])
+    X = float(gold["amplitude"]) * np.random.RandomState(int(gold["seed"])).standard_normal(2 * Nx * Nz)
+    dom = pz.PoiseuilleDomain(Nx, Nz)
+    buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+    args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.125]
+    J = pz.FWD_Solve_Discrete([X], *args)
+    g = pz.ADJ_Solve_Discrete([X], *args)[0]
+    assert abs(J - float(gold["J"])) <= RTOL * abs(float(gold["J"])), (J, float(gold["J"]))
+    nrm = float(gold["grad_norm"])
+    assert abs(np.linalg.norm(g) - nrm) <= RTOL * nrm
+    assert np.linalg.norm(g[gold["idx"]] - gold["grad"]) <= RTOL * np.linalg.norm(gold["grad"])
+    w = np.random.RandomState(77).standard_normal(g.size)
+    assert abs(float(np.dot(g, w)) - float(gold["grad_proj"])) <= RTOL * nrm * np.sqrt(g.size)
+    for key, arr in (("u_last", buf['u_fwd'][:, :, -1]), ("b_last", buf['b_fwd'][:, :, -1]), ("b_prev", buf['b_fwd'][:, :, -2])):
+        ref = gold[key + "_sample"]
+        assert np.linalg.norm(arr.ravel()[::97] - ref) <= 1e-8 * np.linalg.norm(ref), key
+        assert abs(np.linalg.norm(arr) - float(gold[key + "_norm"])) <= 1e-8 * float(gold[key + "_norm"]), key
+    dom.drop_contexts()
