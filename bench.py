@@ -107,7 +107,7 @@ def bench_sh23(a, torch, rank, world):
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     ctx.timing_enable(True)                             # the per-kernel figures come from one more gradient, outside the timed region (an event pair per launch costs time)
-    ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    J = ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
     torch.cuda.synchronize()
     tim = ctx.timing()
     dom_k = max(tim, key=lambda t: t["total_ms"])
@@ -210,7 +210,15 @@ def bench_pois(a, torch, rank, world):
     roof["frac"] = roof["achieved"] / roof["peak"]
     cfg = {"workload": "Plane-Poiseuille optimal mixing (Discrete), Nx x Nz = %d x %d, Re=500, Ri=0.05, T=%g, dt=%g, mix-norm cost"
                        % (Nx, Nz, dt * n_iters, dt),
-           "grid": [Nx, Nz], "n_iters": n_iters, "operator_build_s": build_s, "parallelism": "replicas only (x%d)" % world}
+           "grid": [Nx, Nz], "n_iters": n_iters, "operator_build_s": build_s, "J": J, "parallelism": "replicas only (x%d)" % world}
+    fx = os.path.join(ROOT, "tests", "golden", "oracle_poiseuille_%dx%d_n%d_s1.npz" % (Nx, Nz, n_iters))     # expected value of exactly this workload (data, not oracle code)
+    if rank == 0 and os.path.exists(fx):
+        try:
+            Jo = float(np.load(fx)["J"])
+            cfg["J_oracle_fixture"] = Jo
+            cfg["J_matches_oracle_1e-6"] = bool(abs(J - Jo) <= 1e-6 * abs(Jo))
+        except Exception:
+            pass
     return steps, warm, el, 1, roof, cfg, None
 
 
@@ -607,7 +615,7 @@ def main():
             st, wm, e2, units, rf, cf, _ = fn(b, torch, rank, world)
             secondary.append({"workload": cf["workload"], "value": st * units / e2, "unit": "gradient evals/s", "ms_per_step": 1e3 * e2 / st,
                               "us_per_time_step": (1e6 * e2 / st / (2 * cf["n_iters"])) if fn is bench_pois else rf["avg_launch_ms"] * 1e3 / cf["n_iters"],
-                              "steps": st, "warmup": wm})
+                              "steps": st, "warmup": wm, **{k: cf[k] for k in ("J", "J_matches_oracle_1e-6") if k in cf}})
         # BASELINE configs[4]'s grid on this ONE GPU (windowed checkpoints): the 1-GPU end of the 256^3 strong-scaling series whose
         # N-GPU points the N > 1 runs report under the same key
         if wl == "kdyn" and a.npts is None and a.iters is None:
