@@ -205,13 +205,15 @@ def test_continuous_hodlr_apply_matches_dense_apply(Nx, Nz, n, s, monkeypatch):
     assert rel(gh, gd) < 1e-11 and rel(bh, bd) < 1e-11, (rel(gh, gd), rel(bh, bd))
 
 
-def test_reference_resolution_full_length_fixture():
-    """The workload of bench.py's Poiseuille line — 384 x 192, 1000 steps (T = 5), mix-norm cost, the same seeded input — against the oracle
-    run committed as tests/golden/oracle_poiseuille_384x192_n1000_s1.npz (tools/gen_golden_poiseuille_full.py): the HODLR operators, the
-    fused epilogues and the in-place snapshot reads at the size and length that is timed."""
-    path = os.path.join(GOLDEN, "oracle_poiseuille_384x192_n1000_s1.npz")
+@pytest.mark.parametrize("sw", [1, 0])
+def test_reference_resolution_full_length_fixture(sw):
+    """The workload of bench.py's Poiseuille line — 384 x 192, 1000 steps (T = 5), mix-norm cost (sw = 1; sw = 0: the kinetic-energy cost with
+    its forcing terms), the same seeded input — against the oracle runs committed as tests/golden/oracle_poiseuille_384x192_n1000_s<sw>.npz
+    (tools/gen_golden_poiseuille_full.py): the HODLR operators, the fused epilogues and the in-place snapshot reads at the size and length
+    that is timed."""
+    path = os.path.join(GOLDEN, "oracle_poiseuille_384x192_n1000_s%d.npz" % sw)
     if not os.path.exists(path):
-        pytest.skip("tests/golden/oracle_poiseuille_384x192_n1000_s1.npz not generated (tools/gen_golden_poiseuille_full.py)")
+        pytest.skip("%s not generated (tools/gen_golden_poiseuille_full.py)" % os.path.basename(path))
     gold = np.load(path)
     Nx, Nz, n, s = int(gold["Nx"]), int(gold["Nz"]), int(gold["steps"]), int(gold["s"])
     X = float(gold["amplitude"]) * np.random.RandomState(int(gold["seed"])).standard_normal(2 * Nx * Nz)
