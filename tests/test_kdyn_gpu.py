@@ -175,6 +175,16 @@ def test_config5_fixture():
     _fixture_run("oracle_kdyn_c5_256_n2.npz")
 
 
+@pytest.mark.parametrize("ckpt", [2, 4])
+def test_config5_fixture_more_steps_with_windowed_checkpoints(ckpt):
+    """256^3, 9 steps, all four combinations, with the checkpoint windows (and the Ty cache of a window) the 1000-step run on one GPU uses:
+    tests/golden/oracle_kdyn_c5_256_n9.npz (tools/gen_golden_kdyn_big.py --npts 256 --steps 9).  Windows of 2 and of 4 steps (4 does not
+    divide 9): the composition of the G = 384 kernels with the recomputation, which the 2-step fixture cannot show."""
+    if not os.path.exists(os.path.join(GOLDEN, "oracle_kdyn_c5_256_n9.npz")):
+        pytest.skip("tests/golden/oracle_kdyn_c5_256_n9.npz not generated (tools/gen_golden_kdyn_big.py --npts 256 --steps 9: half an hour of CPU)")
+    _fixture_run("oracle_kdyn_c5_256_n9.npz", ckpt=ckpt)
+
+
 def test_taylor_remainder_two_fields():
     """Adjoint_Gradient_Test on the HIP path with both dB and dU perturbed."""
     N, n, dt = 16, 10, 1e-2
