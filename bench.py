@@ -96,6 +96,7 @@ def bench_sh23(a, torch, rank, world):
     Gd = torch.empty_like(Xd)
     for _ in range(warm):
         ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    ctx.timing_enable(True)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -106,9 +107,6 @@ def bench_sh23(a, torch, rank, world):
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
-    ctx.timing_enable(True)                             # the per-kernel figures come from one more gradient, outside the timed region (an event pair per launch costs time)
-    J = ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
-    torch.cuda.synchronize()
     tim = ctx.timing()
     dom_k = max(tim, key=lambda t: t["total_ms"])
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
@@ -185,26 +183,32 @@ def bench_pois(a, torch, rank, world):
     X = 1e-3 * np.random.RandomState(42 + rank).standard_normal(2 * Nx * Nz)
     Xd = torch.from_numpy(X).cuda()
     Gd = torch.empty_like(Xd)
-    for _ in range(warm):
-        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    # warm-up passes time EVERY kernel class (the breakdown in `all_kernels`); the timed region then records HIP events only around the launches
+    # of the HBM-bound class that takes longest (an operator apply), so that the instrumentation does not slow the other 13 launches of a
+    # step pair (the path is bound by the hand-over between short dependent kernels)
     ctx.timing_enable(True)
+    for _ in range(max(warm, 1)):
+        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+    tim_all = ctx.timing()
+    dom_i = max(range(len(tim_all)), key=lambda i: tim_all[i]["total_ms"] if tim_all[i]["bytes_per_launch"] > 0 else -1.0)
+    ctx.timing_enable(only=dom_i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
+        J = ctx.forward_dev([Xd]); ctx.adjoint_dev([Xd], [Gd])
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     tim = ctx.timing()
-    dom_k = max(tim, key=lambda t: t["total_ms"] if t["bytes_per_launch"] > 0 else -1.0)     # the HBM-bound kernel: the operator apply (the MFMA GEMMs are launch-bound)
+    dom_k = tim[dom_i]                                  # the HBM-bound kernel: an operator apply (the MFMA GEMMs are launch-bound); timed live in the region above
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms,
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1),
-                             "GBps": t["bytes_per_launch"] * t["launches"] / max(t["total_ms"], 1e-9) / 1e6} for t in tim],
+                             "GBps": t["bytes_per_launch"] * t["launches"] / max(t["total_ms"], 1e-9) / 1e6} for t in tim_all],
             "note": "bytes_per_launch = the tau operators one launch streams (HODLR form; the mean of the forward apply over the de-aliased "
                     "wavenumbers or the transposed apply over all of them, whichever class took longer)"}
     roof["frac"] = roof["achieved"] / roof["peak"]
