@@ -3,14 +3,15 @@
 // Replaces FWD_Solve_Discrete / ADJ_Solve_Discrete / Inner_Prod_Discrete and the transform helpers of
 // Example_Problems/Bounded_Domain(Cheby)/Optimal_Mixing/FWD_Solve_Poiseuille.py (:777-1155, :1320-1659, :282-299, :44-118).
 //
-// The reference steps an 8-variable Dedalus LBVP per x-wavenumber with SciPy DCTs and hand-written transposed solves.  Here the
-// whole path is cast as dense fp64 matrix products on the matrix cores (v_mfma_f64_16x16x4_f64):
-//   * every transform and its adjoint is a pair of small GEMMs: a z matrix (Nz x Nz: Chebyshev grid <-> T coefficients, with the
-//     z derivative / de-aliasing mask folded in where needed) and an x matrix (Nx x 2a: Hermitian half spectrum <-> real grid, with
-//     d/dx folded in) — the adjoint transforms are the transposed z matrices, so the discrete adjoint is exact by construction;
-//   * the tau solve of the LBVP is the dense map  S_k : (rhs_u, rhs_v, rhs_rho) -> (u, v, rho, uz, vz, rhoz)  per wavenumber
-//     (built once on the host by a banded pivoted LU of the tau system), applied as a batched complex GEMV; the reference's
-//     transposed solve  P^L^H A^-H P^R^H  is S_k^H.
+// The reference steps an 8-variable Dedalus LBVP per x-wavenumber with SciPy DCTs and hand-written transposed solves.  Here:
+//   * every transform and its adjoint is a z part and an x part.  The z part is a small dense fp64 GEMM on the matrix cores
+//     (v_mfma_f64_16x16x4_f64) with an Nz x Nz matrix (Chebyshev grid <-> T coefficients, with the z derivative / de-aliasing mask folded
+//     in where needed) — the adjoint transforms are the transposed z matrices, so the discrete adjoint is exact by construction.  The x
+//     part (Hermitian half spectrum <-> real grid, with d/dx, 1/Nx or the 2/3 mask as a per-mode factor) is an LDS FFT (pois_x_to_grid /
+//     pois_x_to_coeff) where Nx has an instantiation, else a GEMM with the Nx x 2a matrix of the same map;
+//   * the tau solve of the LBVP is the map  S_k : (rhs_u, rhs_v, rhs_rho) -> (u, v, rho, uz, vz, rhoz)  per wavenumber (built once on
+//     the host by a banded pivoted LU of the tau system), stored and applied in HODLR form (hodlr.hpp; SMO_POIS_APPLY=dense: as a dense
+//     batched complex GEMV); the reference's transposed solve  P^L^H A^-H P^R^H  is S_k^H, packed from the same factors.
 // Real fields => only the a = Nx/2 non-negative wavenumbers n = 0..kmax are carried (the reference carries the full complex spectrum of
 // a complex-dtype domain, POIS:338; the negative half is the Hermitian mirror).  The forward state lives in the de-aliased modes
 // n < ada = (2Nx/3)/2 only; the adjoint state does not (the reference's transposed solves run on every pencil), so the adjoint carries all.
@@ -22,6 +23,7 @@
 #include <thread>
 
 #include "smo_common.hpp"
+#include "fft_lds.hpp"
 #include "hodlr.hpp"
 
 namespace smo {
@@ -115,6 +117,98 @@ __global__ __launch_bounds__(256) void pois_gemm(const GemmDesc* __restrict__ de
 constexpr int GEMM_T = 32;
 static inline void launch_gemm(hipStream_t stream, const GemmDesc* descs, int n, int M, int N, int K, long long shift = 0) {
     hipLaunchKernelGGL((pois_gemm<GEMM_T, GEMM_T>), dim3((N + GEMM_T - 1) / GEMM_T, (M + GEMM_T - 1) / GEMM_T, n), dim3(256), 0, stream, descs, M, N, K, shift);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x transforms as FFTs.  Every x matrix of the Discrete path is a real DFT of length Nx composed with a per-mode factor:
+//     coefficients -> grid   g[x] = sum_{|n| < a} f_n c_n e^{+2 pi i n x / Nx}      Xi: f = 1;  XiD: i k;  XiN: 1/Nx;  XiN_DA: 1/Nx for n < ada, else 0
+//     grid -> coefficients   c_n  = f_n sum_x g[x] e^{-2 pi i n x / Nx}             Xf: 1/Nx;  Xf_DA: 1/Nx for n < ada, else 0;  XfN: 1;  XfNDa: -i k
+// (a = Nx/2 modes, no Nyquist mode; fields [2a][Nz]: row 2n = Re, 2n+1 = Im; grids [Nx][Nz]).  The dense products with those matrices are
+// 60 % of the path's flops (2 Nx^2 Nz per field against 5 Nx log2(Nx) Nz); here two z columns share one complex transform of length Nx
+// (LDS Stockham stages of fft_lds.hpp), ZT columns per workgroup.  Lengths with an instantiation below; otherwise the dense products stay.
+// ---------------------------------------------------------------------------------------------------------
+enum { XK_I = 0, XK_ID = 1, XK_IN = 2, XK_IN_DA = 3, XK_F = 4, XK_F_DA = 5, XK_FN = 6, XK_FNDA = 7 };
+struct XDesc { const double* src; double* dst; int kind; };
+#ifndef SMO_POIS_X_ZT
+#define SMO_POIS_X_ZT 8
+#endif
+constexpr int X_ZT = SMO_POIS_X_ZT, X_NT = 256;          // z columns per workgroup: X_ZT / 2 packed transforms, consecutive lanes on consecutive columns
+
+template <int L>
+__global__ __launch_bounds__(X_NT) void pois_x_to_grid(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int ada, double k1) {
+    constexpr int NB = X_ZT / 2, a = L / 2;
+    __shared__ cplx buf[NB * L];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += X_NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const XDesc d = descs[blockIdx.y];
+    const int z0 = blockIdx.x * X_ZT;
+    auto mode = [&](int n, int z) -> cplx {                 // f_n c_n of column z (Im c_0 does not enter a real field: the dense matrix has a zero there)
+        if (z >= Nz) return mk(0, 0);
+        const double re = d.src[(size_t)(2 * n) * Nz + z], im = n == 0 ? 0.0 : d.src[(size_t)(2 * n + 1) * Nz + z];
+        switch (d.kind) {
+            case XK_ID: { const double k = k1 * n; return mk(-k * im, k * re); }
+            case XK_IN: return mk(re / L, im / L);
+            case XK_IN_DA: return n < ada ? mk(re / L, im / L) : mk(0, 0);
+            default: return mk(re, im);
+        }
+    };
+    auto ld0 = [&](int b, int pos) -> cplx {                // packed Hermitian spectrum of the columns z0 + 2b (real part) and z0 + 2b + 1 (imaginary part)
+        if (pos == a) return mk(0, 0);
+        const int n = pos < a ? pos : L - pos;
+        const cplx A = mode(n, z0 + 2 * b), B = mode(n, z0 + 2 * b + 1);
+        return pos < a ? mk(A.re - B.im, A.im + B.re) : mk(A.re + B.im, B.re - A.im);
+    };
+    auto stN = [&](int b, int x, cplx v) {
+        const int z = z0 + 2 * b;
+        if (z + 1 < Nz) *reinterpret_cast<cplx*>(d.dst + (size_t)x * Nz + z) = v;       // Nz and z are even: 16-byte aligned
+        else if (z < Nz) d.dst[(size_t)x * Nz + z] = v.re;
+    };
+    fft_inplace_ix<L, true, NB, X_NT, true, false, false>(buf, PosMajor<NB>{}, tw, tid, ld0, stN);
+}
+
+template <int L>
+__global__ __launch_bounds__(X_NT) void pois_x_to_coeff(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int ada, double k1) {
+    constexpr int NB = X_ZT / 2, a = L / 2;
+    __shared__ cplx buf[NB * L];
+    __shared__ cplx tw[L];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += X_NT) tw[i] = tw_g[i];
+    __syncthreads();
+    const XDesc d = descs[blockIdx.y];
+    const int z0 = blockIdx.x * X_ZT;
+    auto ld0 = [&](int b, int x) -> cplx {
+        const int z = z0 + 2 * b;
+        if (z + 1 < Nz) return *reinterpret_cast<const cplx*>(d.src + (size_t)x * Nz + z);
+        return z < Nz ? mk(d.src[(size_t)x * Nz + z], 0.0) : mk(0, 0);
+    };
+    constexpr PosMajor<NB> ix{};
+    fft_inplace_ix<L, false, NB, X_NT, true, false, true>(buf, ix, tw, tid, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
+    __syncthreads();
+    for (int t = tid; t < X_ZT * a; t += X_NT) {            // Hermitian split: column z0 + q of mode n
+        const int q = t % X_ZT, n = t / X_ZT, b = q >> 1, z = z0 + q;
+        if (z >= Nz) continue;
+        const cplx hl = buf[ix(b, n)], hh = n == 0 ? hl : buf[ix(b, L - n)];
+        const cplx F = (q & 1) ? mk(0.5 * (hl.im + hh.im), -0.5 * (hl.re - hh.re)) : mk(0.5 * (hl.re + hh.re), 0.5 * (hl.im - hh.im));
+        cplx c;
+        switch (d.kind) {
+            case XK_F: c = mk(F.re / L, F.im / L); break;
+            case XK_F_DA: c = n < ada ? mk(F.re / L, F.im / L) : mk(0, 0); break;
+            case XK_FNDA: { const double k = k1 * n; c = mk(k * F.im, -k * F.re); break; }
+            default: c = F;
+        }
+        d.dst[(size_t)(2 * n) * Nz + z] = c.re;
+        d.dst[(size_t)(2 * n + 1) * Nz + z] = n == 0 ? 0.0 : c.im;
+    }
+}
+template <class F> static inline bool with_xfft_length(int Nx, F f) {
+    switch (Nx) {
+#define SMO_POIS_X(n) case n: f(std::integral_constant<int, n>()); return true;
+        SMO_POIS_X(24) SMO_POIS_X(30) SMO_POIS_X(36) SMO_POIS_X(48) SMO_POIS_X(60) SMO_POIS_X(96) SMO_POIS_X(192) SMO_POIS_X(384) SMO_POIS_X(768)
+#undef SMO_POIS_X
+    }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -617,15 +711,42 @@ public:
     int k_gemm = -1, k_apply = -1, k_apply_adj = -1, k_point = -1;
     double op_bytes = 0.0, op_bytes_adj = 0.0;
 
-    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
+    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; XDesc* xd = nullptr; int xdir = 0; };   // xdir: +1 coefficients -> grid, -1 grid -> coefficients, 0 not an x phase
+    bool use_xfft = false;                                                          // the x phases as FFTs (SMO_POIS_XFFT=0: the dense products)
+    cplx* d_twx = nullptr;
+    int k_xfft = -1;
     Phase F0x, F0z, F0d, Fz1, Fz, Fx, Fxf, Fzf, M1z, M1x, T0z, T0x, T0xf, T0zf, T1xf, T1zf, Ad, Az, Ax, Axf, Azf, Gd, Gz, Gx;
 
     int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
         p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
+        // a phase whose left factors are all x matrices of one direction can run as FFTs (pois_x_to_grid / pois_x_to_coeff)
+        std::vector<XDesc> xv;
+        int dir = 0;
+        for (const GemmDesc& g : v) {
+            int kind = -1;
+            if (g.A == A_Xi) kind = XK_I; else if (g.A == A_XiD) kind = XK_ID; else if (g.A == A_XiN) kind = XK_IN; else if (g.A == A_XiN_DA) kind = XK_IN_DA;
+            else if (g.A == A_Xf) kind = XK_F; else if (g.A == A_Xf_DA) kind = XK_F_DA; else if (g.A == A_XfN) kind = XK_FN; else if (g.A == A_XfNDa) kind = XK_FNDA;
+            const int dd = kind < 0 ? 0 : (kind < XK_F ? 1 : -1);
+            if (kind < 0 || g.E || g.X || g.dyn || (dir != 0 && dd != dir)) { dir = 0; xv.clear(); break; }
+            dir = dd;
+            xv.push_back({g.B, g.C, kind});
+        }
+        p.xdir = dir;
+        if (dir != 0) SMO_TRY(pool.upload(&p.xd, xv, stream));
         return pool.upload(&p.d, v, stream);
     }
     int run(const Phase& p, int count = -1, long long shift = 0) {
         const int n = count < 0 ? p.n : count;
+        if (use_xfft && p.xdir != 0) {
+            ScopedTimer t(timing, k_xfft, stream);
+            const dim3 grid((unsigned)((Nz + X_ZT - 1) / X_ZT), (unsigned)n);
+            with_xfft_length(Nx, [&](auto l) {
+                constexpr int L = decltype(l)::value;
+                if (p.xdir > 0) hipLaunchKernelGGL(pois_x_to_grid<L>, grid, dim3(X_NT), 0, stream, p.xd, d_twx, Nz, ada, k1);
+                else hipLaunchKernelGGL(pois_x_to_coeff<L>, grid, dim3(X_NT), 0, stream, p.xd, d_twx, Nz, ada, k1);
+            });
+            return SMO_OK;
+        }
         ScopedTimer t(timing, k_gemm, stream);
         launch_gemm(stream, p.d, n, p.M, p.N, p.K, shift);
         return SMO_OK;
@@ -736,6 +857,11 @@ public:
         for (int x = 0; x < Nx; ++x) for (int c = 2 * ada; c < 2 * a; ++c) XiN[(size_t)x * 2 * a + c] = 0.0;     // de-aliasing mask in x
         for (int r = 2 * ada; r < 2 * a; ++r) for (int x = 0; x < Nx; ++x) Xf[(size_t)r * Nx + x] = 0.0;
         SMO_TRY(pool.upload(&A_XiN_DA, XiN, stream)); SMO_TRY(pool.upload(&A_Xf_DA, Xf, stream));
+        {
+            const char* e = getenv("SMO_POIS_XFFT");
+            use_xfft = !(e && atoi(e) == 0) && Nz % 2 == 0 && with_xfft_length(Nx, [](auto) {});
+            if (use_xfft) SMO_TRY(pool.upload(&d_twx, twiddles(Nx), stream));
+        }
         // ---- base state rho = -erf(z/delta)/2 (n = 0 only), de-aliased (POIS:932-936) ------------------------------------------------
         {
             std::vector<double> r0(nC, 0.0), rz0(nC, 0.0);
@@ -870,6 +996,7 @@ public:
         k_apply = timing.add_class(use_hodlr ? "pois_apply_hodlr (tau operator, HODLR form)" : "pois_apply (tau operator, batched complex GEMV)", op_bytes, op_bytes);
         k_apply_adj = timing.add_class(use_hodlr ? "pois_apply_hodlr (transposed tau operator)" : "pois_apply (transposed tau operator)", op_bytes_adj, op_bytes_adj);
         k_point = timing.add_class("pois pointwise", 0.0);
+        k_xfft = timing.add_class("pois_x (x transforms, LDS FFT)", 0.0);
         return SMO_OK;
     }
 

@@ -233,3 +233,23 @@ def test_reference_resolution_full_length_fixture(sw):
         assert np.linalg.norm(arr.ravel()[::97] - ref) <= 1e-8 * np.linalg.norm(ref), key
         assert abs(np.linalg.norm(arr) - float(gold[key + "_norm"])) <= 1e-8 * float(gold[key + "_norm"]), key
     dom.drop_contexts()
+
+
+@pytest.mark.parametrize("Nx,Nz,n,s", [(24, 24, 5, 0), (30, 66, 5, 1), (36, 48, 4, 0), (96, 48, 4, 1), (384, 192, 6, 1), (384, 192, 3, 0), (60, 36, 3, 1)])
+def test_x_transforms_as_ffts_match_the_dense_products(Nx, Nz, n, s, monkeypatch):
+    """The x phases as LDS FFTs (pois_x_to_grid / pois_x_to_coeff, the default where Nx has an instantiation) against the dense products with
+    the x matrices (SMO_POIS_XFFT=0): cost, gradient and snapshots to 1e-11, including a ragged last tile of z columns (Nz = 66)."""
+    _, U0 = pz.Generate_IC(Nx, Nz, E_0=0.02, seed=11)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SMO_POIS_XFFT", mode)
+        dom = pz.PoiseuilleDomain(Nx, Nz)
+        buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+        args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.125]
+        J = pz.FWD_Solve_Discrete(U0, *args)
+        g = pz.ADJ_Solve_Discrete(U0, *args)[0]
+        res[mode] = (J, g, buf['u_fwd'][:, :, -1].copy(), buf['b_fwd'][:, :, -2].copy())
+        dom.drop_contexts()
+    (Jd, gd, ud, bd), (Jf, gf, uf, bf) = res["0"], res["1"]
+    assert abs(Jf - Jd) <= 1e-11 * abs(Jd), (Jf, Jd)
+    assert rel(gf, gd) < 1e-11 and rel(uf, ud) < 1e-11 and rel(bf, bd) < 1e-11, (rel(gf, gd), rel(uf, ud), rel(bf, bd))
