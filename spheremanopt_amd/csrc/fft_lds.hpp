@@ -1,7 +1,7 @@
 // LDS-staged Stockham autosort FFT for gfx950, complex128.
 //
 // A length-L transform is a chain of decimation-in-frequency Stockham stages of radix [8, then] 4, then 2, then 5, then 3
-// (L = 4^a 2^b 5^d 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..480 incl. 36 = 4*3*3 for Npts = 24 and 30..480 = 3 * Npts/2
+// (L = 4^a 2^b 5^d 7^e 3^c, b in {0,1}; covers 2^k and the 3/2-dealiased sizes 12..480 incl. 36 = 4*3*3 for Npts = 24 and 30..480 = 3 * Npts/2
 // for Npts = 20, 40, 80, 160, 320).  Stage invariant n*s == L:
 //     y[q + s*(R*p + j)] = w_n^{p*j} * sum_k x[q + s*(p + k*n/R)] * w_R^{j*k},  0 <= p < n/R, 0 <= q < s
 // so (i) the R inputs of consecutive butterflies are consecutive 16-byte elements (conflict-free ds_read_b128 /
@@ -20,14 +20,15 @@ namespace smo {
 #ifndef SMO_FFT_MAX_RADIX
 #define SMO_FFT_MAX_RADIX 4
 #endif
-constexpr __host__ __device__ int radix_of(int n) {      // 5 before 3: a length with a factor 3 (every 3/2-dealiased grid) ends on radix 3
-    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : ((n % 5 == 0) ? 5 : 3)));
+constexpr __host__ __device__ int radix_of(int n) {      // 5 and 7 before 3: a length with a factor 3 (every 3/2-dealiased grid) ends on radix 3
+    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : ((n % 5 == 0) ? 5 : ((n % 7 == 0) ? 7 : 3))));
 }
 constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + stage_count(n / radix_of(n)); }
 constexpr bool fft_length_ok(int n) {
     while (n % 4 == 0) n /= 4;
     if (n % 2 == 0) n /= 2;
     while (n % 5 == 0) n /= 5;
+    while (n % 7 == 0) n /= 7;
     while (n % 3 == 0) n /= 3;
     return n == 1;
 }
@@ -62,6 +63,20 @@ template <bool INV> struct Butterfly<5, INV> {
         const cplx r1 = rot90<INV>(mk(S1 * t3.re + S2 * t4.re, S1 * t3.im + S2 * t4.im));
         const cplx r2 = rot90<INV>(mk(S2 * t3.re - S1 * t4.re, S2 * t3.im - S1 * t4.im));
         v[0] = v[0] + t1 + t2; v[1] = a1 + r1; v[2] = a2 + r2; v[3] = a2 - r2; v[4] = a1 - r1;
+    }
+};
+template <bool INV> struct Butterfly<7, INV> {
+    static __device__ __forceinline__ void run(cplx (&v)[7]) {
+        const double C1 = 0.62348980185873353052500488400424, C2 = -0.22252093395631440428890256449679, C3 = -0.90096886790241912623610231950745;   // cos(2 pi j/7)
+        const double S1 = 0.78183148246802980870844452667406, S2 = 0.97492791218182360701813168299393, S3 = 0.43388373911755812047576833284836;    // sin(2 pi j/7)
+        const cplx t1 = v[1] + v[6], t2 = v[2] + v[5], t3 = v[3] + v[4], d1 = v[1] - v[6], d2 = v[2] - v[5], d3 = v[3] - v[4];
+        const cplx a1 = mk(v[0].re + C1 * t1.re + C2 * t2.re + C3 * t3.re, v[0].im + C1 * t1.im + C2 * t2.im + C3 * t3.im);
+        const cplx a2 = mk(v[0].re + C2 * t1.re + C3 * t2.re + C1 * t3.re, v[0].im + C2 * t1.im + C3 * t2.im + C1 * t3.im);
+        const cplx a3 = mk(v[0].re + C3 * t1.re + C1 * t2.re + C2 * t3.re, v[0].im + C3 * t1.im + C1 * t2.im + C2 * t3.im);
+        const cplx r1 = rot90<INV>(mk(S1 * d1.re + S2 * d2.re + S3 * d3.re, S1 * d1.im + S2 * d2.im + S3 * d3.im));
+        const cplx r2 = rot90<INV>(mk(S2 * d1.re - S3 * d2.re - S1 * d3.re, S2 * d1.im - S3 * d2.im - S1 * d3.im));
+        const cplx r3 = rot90<INV>(mk(S3 * d1.re - S1 * d2.re + S2 * d3.re, S3 * d1.im - S1 * d2.im + S2 * d3.im));
+        v[0] = v[0] + t1 + t2 + t3; v[1] = a1 + r1; v[2] = a2 + r2; v[3] = a3 + r3; v[4] = a3 - r3; v[5] = a2 - r2; v[6] = a1 - r1;
     }
 };
 template <bool INV> struct Butterfly<4, INV> {

@@ -829,10 +829,10 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
-        static const int sizes[] = {8, 12, 16, 20, 24, 32, 36, 40, 48, 60, 64, 72, 80, 96, 100, 120, 128, 144, 160, 192, 200, 240, 256, 320};
+        static const int sizes[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 100, 112, 120, 128, 144, 160, 192, 200, 224, 240, 256, 320};
         if (std::find(std::begin(sizes), std::end(sizes), N) == std::end(sizes)) {
-            // the transform lengths G = 3N/2 are compile-time instantiations (factors 2, 3 and 5); the reference, through FFTW, takes any even Npts
-            set_error("KDYN: npts must be one of 8,12,16,20,24,32,36,40,48,60,64,72,80,96,100,120,128,144,160,192,200,240,256,320 (got %d)", N);
+            // the transform lengths G = 3N/2 are compile-time instantiations (factors 2, 3, 5 and 7); the reference, through FFTW, takes any even Npts
+            set_error("KDYN: npts must be one of 8,12,16,20,24,28,32,36,40,48,56,60,64,72,80,96,100,112,120,128,144,160,192,200,224,240,256,320 (got %d)", N);
             return SMO_ERR_UNSUPPORTED;
         }
         if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
@@ -947,6 +947,10 @@ public:
             case 360: return f(std::integral_constant<int, 360>());
             case 150: return f(std::integral_constant<int, 150>());
             case 300: return f(std::integral_constant<int, 300>());
+            case 42: return f(std::integral_constant<int, 42>());      // Npts = 28, 56, 112, 224: one radix-7 stage
+            case 84: return f(std::integral_constant<int, 84>());
+            case 168: return f(std::integral_constant<int, 168>());
+            case 336: return f(std::integral_constant<int, 336>());
             case 18: return f(std::integral_constant<int, 18>());      // Npts = 12, 36, 72, 144: 3 more than once
             case 54: return f(std::integral_constant<int, 54>());
             case 108: return f(std::integral_constant<int, 108>());

@@ -259,10 +259,11 @@ public:
             SMO_SH_CASE(24) SMO_SH_CASE(48) SMO_SH_CASE(96) SMO_SH_CASE(192) SMO_SH_CASE(384) SMO_SH_CASE(768)          // 3 * 2^k
             SMO_SH_CASE(20) SMO_SH_CASE(40) SMO_SH_CASE(80) SMO_SH_CASE(160) SMO_SH_CASE(320) SMO_SH_CASE(640)          // 5 * 2^k
             SMO_SH_CASE(60) SMO_SH_CASE(120) SMO_SH_CASE(240) SMO_SH_CASE(480) SMO_SH_CASE(960)                         // 15 * 2^k
+            SMO_SH_CASE(28) SMO_SH_CASE(56) SMO_SH_CASE(112) SMO_SH_CASE(224) SMO_SH_CASE(448) SMO_SH_CASE(896)         // 7 * 2^k
 #undef SMO_SH_CASE
             case 1024: return f(std::integral_constant<int, 1024>());
         }
-        set_error("SH23: npts must be 2^k, 3*2^k, 5*2^k or 15*2^k in [16, 1024] (got %d)", NH);
+        set_error("SH23: npts must be 2^k, 3*2^k, 5*2^k, 7*2^k or 15*2^k in [16, 1024] (got %d)", NH);
         return SMO_ERR_UNSUPPORTED;
     }
 

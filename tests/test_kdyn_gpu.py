@@ -31,7 +31,8 @@ def _fields(G, dirty=False):
 
 _SMALL = [(8, 3, 1e-2, True), (16, 6, 1e-2, True), (32, 4, 1e-3, False), (64, 2, 1e-3, True),
           (20, 3, 1e-2, True), (40, 3, 1e-3, True),         # G = 30, 60: lengths with a radix-5 stage
-          (12, 3, 1e-2, True), (36, 2, 1e-3, True)]         # G = 18, 54: the factor 3 more than once
+          (12, 3, 1e-2, True), (36, 2, 1e-3, True),         # G = 18, 54: the factor 3 more than once
+          (28, 3, 1e-2, True)]                              # G = 42: a radix-7 stage
 _ALL4 = [(c, a) for c in ("Final", "Integrated") for a in ("Discrete", "Continuous")]
 # every cost / adjoint combination inline up to 64^3; the default one also at 96^3 and 128^3 (the other three at 128^3 — and 256^3 — are
 # compared with the committed oracle fixtures below: 50 / 2 steps of all four, test_config4_fixture / test_config5_fixture)
@@ -39,7 +40,8 @@ _CASES = [(N, n, dt, d, c, a) for (N, n, dt, d) in _SMALL for (c, a) in _ALL4] +
          [(96, 1, 1e-3, False, "Final", "Discrete"), (96, 1, 1e-3, True, "Integrated", "Continuous"), (128, 2, 1e-3, False, "Final", "Discrete"),
           (80, 2, 1e-3, True, "Final", "Discrete"), (80, 2, 1e-3, False, "Integrated", "Continuous"), (160, 1, 1e-3, True, "Final", "Discrete"),
           (60, 2, 1e-3, True, "Final", "Discrete"), (60, 2, 1e-3, False, "Integrated", "Continuous"), (72, 1, 1e-3, True, "Integrated", "Discrete"),
-          (100, 1, 1e-3, True, "Final", "Continuous"), (120, 1, 1e-3, True, "Final", "Discrete")]      # G = 90, 108, 150, 180
+          (100, 1, 1e-3, True, "Final", "Continuous"), (120, 1, 1e-3, True, "Final", "Discrete"),      # G = 90, 108, 150, 180
+          (56, 2, 1e-3, True, "Integrated", "Discrete"), (112, 1, 1e-3, True, "Final", "Discrete")]      # G = 84, 168
 
 
 @pytest.mark.parametrize("N,n,dt,dirty,cost,adj", _CASES)
@@ -217,11 +219,11 @@ def test_size_independent_properties():
     dom.drop_contexts()
 
 
-@pytest.mark.parametrize("N", [32, 192, 256, 160, 320, 144, 200, 240])
+@pytest.mark.parametrize("N", [32, 192, 256, 160, 320, 144, 200, 240, 224])
 def test_known_answer_single_mode_decay(N):
     """U = 0, B = (0, cos 3x, 0): every CNAB1 step multiplies the mode by (1/dt - 9/2Rm)/(1/dt + 9/2Rm) — an answer that does not
     come from the oracle.  Also dJ/dU = 0 and dJ/dB0 = -2 r^(2N) B0 for the Final cost.  N = 192 (G = 288 = 4*4*2*3*3): a size whose
-    oracle run would take minutes is checked through this closed form; N = 256 (G = 384): the north-star grid's kernel instantiations; N = 160, 320 (G = 240, 480 = 4*4*[2*]5*3): the radix-5 sizes; N = 144, 200, 240 (G = 216, 300, 360): the largest of the sizes with repeated factors 3 and 5."""
+    oracle run would take minutes is checked through this closed form; N = 256 (G = 384): the north-star grid's kernel instantiations; N = 160, 320 (G = 240, 480 = 4*4*[2*]5*3): the radix-5 sizes; N = 144, 200, 240 (G = 216, 300, 360): the largest of the sizes with repeated factors 3 and 5; N = 224 (G = 336 = 4*4*7*3): the largest radix-7 size."""
     n, dt, Rm = 9, 1e-2, 1.3
     dom = kdyn.KDynDomain(N)
     G = dom.G

@@ -24,7 +24,8 @@ def _oracle(Npts, dt, n):
 
 
 @pytest.mark.parametrize("Npts,dt,n", [(16, 0.1, 3), (32, 0.05, 17), (64, 0.1, 40), (128, 0.1, 100), (1024, 0.02, 25),
-                                       (24, 0.1, 10), (96, 0.1, 60), (384, 0.1, 30), (80, 0.1, 40), (640, 0.05, 20), (60, 0.1, 25), (960, 0.05, 12)])
+                                       (24, 0.1, 10), (96, 0.1, 60), (384, 0.1, 30), (80, 0.1, 40), (640, 0.05, 20), (60, 0.1, 25), (960, 0.05, 12),
+                                       (28, 0.1, 10), (112, 0.1, 30), (896, 0.05, 12)])          # 7 * 2^k: a radix-7 stage
 @pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
 def test_forward_adjoint_vs_oracle(Npts, dt, n, adj):
     dom, X = sh23.Generate_IC(0.0725, Npts=Npts, seed=42)
