@@ -134,9 +134,11 @@ struct XDesc { const double* src; double* dst; int kind; };
 #endif
 constexpr int X_ZT = SMO_POIS_X_ZT, X_NT = 256;          // z columns per workgroup: X_ZT / 2 packed transforms, consecutive lanes on consecutive columns
 
+// `a` = modes carried (n < a): L / 2 in the Discrete formulation (grid of Nx points, no Nyquist mode), L / 3 in the Continuous one (Nx modes on
+// the 3/2 grid: the positions a .. L - a of the padded spectrum are zero)
 template <int L>
-__global__ __launch_bounds__(X_NT) void pois_x_to_grid(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int ada, double k1) {
-    constexpr int NB = X_ZT / 2, a = L / 2;
+__global__ __launch_bounds__(X_NT) void pois_x_to_grid(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int a, int ada, double k1) {
+    constexpr int NB = X_ZT / 2;
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(X_NT) void pois_x_to_grid(const XDesc* __restrict__
         }
     };
     auto ld0 = [&](int b, int pos) -> cplx {                // packed Hermitian spectrum of the columns z0 + 2b (real part) and z0 + 2b + 1 (imaginary part)
-        if (pos == a) return mk(0, 0);
+        if (pos >= a && pos <= L - a) return mk(0, 0);
         const int n = pos < a ? pos : L - pos;
         const cplx A = mode(n, z0 + 2 * b), B = mode(n, z0 + 2 * b + 1);
         return pos < a ? mk(A.re - B.im, A.im + B.re) : mk(A.re + B.im, B.re - A.im);
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(X_NT) void pois_x_to_grid(const XDesc* __restrict__
 }
 
 template <int L>
-__global__ __launch_bounds__(X_NT) void pois_x_to_coeff(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int ada, double k1) {
-    constexpr int NB = X_ZT / 2, a = L / 2;
+__global__ __launch_bounds__(X_NT) void pois_x_to_coeff(const XDesc* __restrict__ descs, const cplx* __restrict__ tw_g, int Nz, int a, int ada, double k1) {
+    constexpr int NB = X_ZT / 2;
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -209,6 +211,32 @@ template <class F> static inline bool with_xfft_length(int Nx, F f) {
 #undef SMO_POIS_X
     }
     return false;
+}
+// the x matrices of a context (null where it has none) -> the kind of map a product with one of them is
+struct XMats { const double *Xi = nullptr, *XiD = nullptr, *XiN = nullptr, *XiN_DA = nullptr, *Xf = nullptr, *Xf_DA = nullptr, *XfN = nullptr, *XfNDa = nullptr; };
+// a phase whose left factors are all x matrices of one direction can run as FFTs: +1 coefficients -> grid, -1 grid -> coefficients, 0 neither
+static int x_phase_descs(const std::vector<GemmDesc>& v, const XMats& m, std::vector<XDesc>& xv) {
+    int dir = 0;
+    xv.clear();
+    for (const GemmDesc& g : v) {
+        int kind = -1;
+        if (g.A == nullptr) kind = -1;
+        else if (g.A == m.Xi) kind = XK_I; else if (g.A == m.XiD) kind = XK_ID; else if (g.A == m.XiN) kind = XK_IN; else if (g.A == m.XiN_DA) kind = XK_IN_DA;
+        else if (g.A == m.Xf) kind = XK_F; else if (g.A == m.Xf_DA) kind = XK_F_DA; else if (g.A == m.XfN) kind = XK_FN; else if (g.A == m.XfNDa) kind = XK_FNDA;
+        const int dd = kind < 0 ? 0 : (kind < XK_F ? 1 : -1);
+        if (kind < 0 || g.E || g.X || g.dyn || (dir != 0 && dd != dir)) { xv.clear(); return 0; }
+        dir = dd;
+        xv.push_back({g.B, g.C, kind});
+    }
+    return dir;
+}
+static inline void launch_x(hipStream_t stream, const XDesc* xd, int n, int dir, int L, int nz, int a, int ada, double k1, const cplx* twx) {
+    const dim3 grid((unsigned)((nz + X_ZT - 1) / X_ZT), (unsigned)n);
+    with_xfft_length(L, [&](auto l) {
+        constexpr int LL = decltype(l)::value;
+        if (dir > 0) hipLaunchKernelGGL(pois_x_to_grid<LL>, grid, dim3(X_NT), 0, stream, xd, twx, nz, a, ada, k1);
+        else hipLaunchKernelGGL(pois_x_to_coeff<LL>, grid, dim3(X_NT), 0, stream, xd, twx, nz, a, ada, k1);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -719,18 +747,8 @@ public:
 
     int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
         p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
-        // a phase whose left factors are all x matrices of one direction can run as FFTs (pois_x_to_grid / pois_x_to_coeff)
         std::vector<XDesc> xv;
-        int dir = 0;
-        for (const GemmDesc& g : v) {
-            int kind = -1;
-            if (g.A == A_Xi) kind = XK_I; else if (g.A == A_XiD) kind = XK_ID; else if (g.A == A_XiN) kind = XK_IN; else if (g.A == A_XiN_DA) kind = XK_IN_DA;
-            else if (g.A == A_Xf) kind = XK_F; else if (g.A == A_Xf_DA) kind = XK_F_DA; else if (g.A == A_XfN) kind = XK_FN; else if (g.A == A_XfNDa) kind = XK_FNDA;
-            const int dd = kind < 0 ? 0 : (kind < XK_F ? 1 : -1);
-            if (kind < 0 || g.E || g.X || g.dyn || (dir != 0 && dd != dir)) { dir = 0; xv.clear(); break; }
-            dir = dd;
-            xv.push_back({g.B, g.C, kind});
-        }
+        const int dir = x_phase_descs(v, XMats{A_Xi, A_XiD, A_XiN, A_XiN_DA, A_Xf, A_Xf_DA, A_XfN, A_XfNDa}, xv);
         p.xdir = dir;
         if (dir != 0) SMO_TRY(pool.upload(&p.xd, xv, stream));
         return pool.upload(&p.d, v, stream);
@@ -739,12 +757,7 @@ public:
         const int n = count < 0 ? p.n : count;
         if (use_xfft && p.xdir != 0) {
             ScopedTimer t(timing, k_xfft, stream);
-            const dim3 grid((unsigned)((Nz + X_ZT - 1) / X_ZT), (unsigned)n);
-            with_xfft_length(Nx, [&](auto l) {
-                constexpr int L = decltype(l)::value;
-                if (p.xdir > 0) hipLaunchKernelGGL(pois_x_to_grid<L>, grid, dim3(X_NT), 0, stream, p.xd, d_twx, Nz, ada, k1);
-                else hipLaunchKernelGGL(pois_x_to_coeff<L>, grid, dim3(X_NT), 0, stream, p.xd, d_twx, Nz, ada, k1);
-            });
+            launch_x(stream, p.xd, n, p.xdir, Nx, Nz, a, ada, k1, d_twx);
             return SMO_OK;
         }
         ScopedTimer t(timing, k_gemm, stream);
@@ -1251,14 +1264,26 @@ public:
            *MN = nullptr, *d_stack = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     int k_gemm = -1, k_apply = -1, k_point = -1;
-    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; };
+    struct Phase { GemmDesc* d = nullptr; int n = 0, M = 0, N = 0, K = 0; XDesc* xd = nullptr; int xdir = 0; };
     Phase F0x, F0z, Fz, Fx, Fxf, Fzf, F1d, A1d, M1z, M1x, Az, Ax, Gz2, Gx2;
+    bool use_xfft = false;                                 // the x phases (Nx modes <-> 3 Nx / 2 grid points) as FFTs (SMO_POIS_XFFT=0: the dense products)
+    cplx* d_twx = nullptr;
+    int k_xfft = -1;
 
     int make_phase(Phase& p, int M, int N, int K, const std::vector<GemmDesc>& v) {
         p.n = (int)v.size(); p.M = M; p.N = N; p.K = K;
+        std::vector<XDesc> xv;
+        XMats m; m.Xi = A_Xi; m.XiD = A_XiD; m.Xf = A_Xf;
+        p.xdir = x_phase_descs(v, m, xv);
+        if (p.xdir != 0) SMO_TRY(pool.upload(&p.xd, xv, stream));
         return pool.upload(&p.d, v, stream);
     }
     int run(const Phase& p) {
+        if (use_xfft && p.xdir != 0) {
+            ScopedTimer t(timing, k_xfft, stream);
+            launch_x(stream, p.xd, p.n, p.xdir, Gx, Gz, a, a, k1, d_twx);
+            return SMO_OK;
+        }
         ScopedTimer t(timing, k_gemm, stream);
         launch_gemm(stream, p.d, p.n, p.M, p.N, p.K);
         return SMO_OK;
@@ -1329,6 +1354,11 @@ public:
                 Xf[(size_t)(2 * n) * Gx + x] = c / Gx;          Xf[(size_t)(2 * n + 1) * Gx + x] = -sn / Gx;
             }
         SMO_TRY(pool.upload(&A_Xi, Xi, stream)); SMO_TRY(pool.upload(&A_XiD, XiD, stream)); SMO_TRY(pool.upload(&A_Xf, Xf, stream));
+        {
+            const char* e = getenv("SMO_POIS_XFFT");
+            use_xfft = !(e && atoi(e) == 0) && Gz % 2 == 0 && with_xfft_length(Gx, [](auto) {});
+            if (use_xfft) SMO_TRY(pool.upload(&d_twx, twiddles(Gx), stream));
+        }
         {
             std::vector<double> b0(nC, 0.0), bz0(nC, 0.0);
             for (int j = 0; j < N; ++j) {
@@ -1435,6 +1465,7 @@ public:
         k_gemm = timing.add_class("pois_gemm (transforms, MFMA f64)", 0.0);
         k_apply = timing.add_class(use_hodlr ? "pois_apply_hodlr (tau operator, HODLR form)" : "pois_apply (tau operator, batched complex GEMV)", op_bytes, op_bytes);
         k_point = timing.add_class("pois pointwise", 0.0);
+        k_xfft = timing.add_class("pois_x (x transforms, LDS FFT)", 0.0);
         return SMO_OK;
     }
 

@@ -253,3 +253,23 @@ def test_x_transforms_as_ffts_match_the_dense_products(Nx, Nz, n, s, monkeypatch
     (Jd, gd, ud, bd), (Jf, gf, uf, bf) = res["0"], res["1"]
     assert abs(Jf - Jd) <= 1e-11 * abs(Jd), (Jf, Jd)
     assert rel(gf, gd) < 1e-11 and rel(uf, ud) < 1e-11 and rel(bf, bd) < 1e-11, (rel(gf, gd), rel(uf, ud), rel(bf, bd))
+
+
+@pytest.mark.parametrize("Nx,Nz,n,s", [(16, 16, 6, 0), (32, 24, 8, 1), (64, 32, 5, 1), (128, 64, 4, 0)])
+def test_continuous_x_transforms_as_ffts_match_the_dense_products(Nx, Nz, n, s, monkeypatch):
+    """Continuous formulation (Nx modes on the 3 Nx / 2 grid: a zero-padded transform): x phases as FFTs against the dense products."""
+    from oracle.poiseuille import PoiseuilleCntsOracle, synthetic_ic_cnts
+    X = synthetic_ic_cnts(PoiseuilleCntsOracle(Nx, Nz, dt=5e-3, N_ITERS=1, s=s, delta=0.3), 9)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SMO_POIS_XFFT", mode)
+        dom = pz.PoiseuilleDomain(Nx, Nz, continuous=True)
+        buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
+        args = [dom, 500., 0.05, n, buf, 5e-3, s, 1., 0.3]
+        J = pz.FWD_Solve_Cnts([X], *args)
+        g = pz.ADJ_Solve_Cnts([X], *args)[0]
+        res[mode] = (J, g, buf['b_fwd'][:, :, -1].copy())
+        dom.drop_contexts()
+    (Jd, gd, bd), (Jf, gf, bf) = res["0"], res["1"]
+    assert abs(Jf - Jd) <= 1e-11 * abs(Jd), (Jf, Jd)
+    assert rel(gf, gd) < 1e-11 and rel(bf, bd) < 1e-11, (rel(gf, gd), rel(bf, bd))
