@@ -249,7 +249,7 @@ def test_known_answer_single_mode_decay(N):
 
 def test_errors():
     with pytest.raises(_capi.SmoError):
-        _capi.Context(_capi.SMO_KDYN, 28, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size (G = 42 has a factor 7)
+        _capi.Context(_capi.SMO_KDYN, 44, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size (G = 66 has a factor 11)
     ctx = _capi.Context(_capi.SMO_KDYN, 8, (0., 2 * np.pi), 1e-3, 2, 1.0)
     with pytest.raises(_capi.SmoError) as e:
         ctx.adjoint(None)
