@@ -761,6 +761,11 @@ __global__ __launch_bounds__(256) void kd_dot(const double* __restrict__ x, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// the same passes with the transform length a run-time value: every even Npts without a tuned instantiation
+// ---------------------------------------------------------------------------------------------------------
+#include "kdyn_any.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 constexpr int NPART = 1024;         // workgroups (= partial sums) of the reduction kernels
@@ -816,7 +821,8 @@ public:
     Geom geom(int nfields, int k = 0) const { Geom q = g; q.blk = (size_t)nfields * tzc; q.cblk = (size_t)cfg.world * 2 * tzc; q.zg0 = k * g.Gzl; return q; }
     int set_chunks(int k) {
         const int Gzc = k > 0 ? g.Gzr / k : 0;
-        if (k < 1 || g.Gzr % k != 0 || (Gzc & 1) || ((size_t)g.G * Gzc) % 4 != 0) {
+        // (one chunk of one slab may have any shape: odd G runs the run-time-length kernels, which pair its last line with zeros)
+        if (k < 1 || g.Gzr % k != 0 || ((k > 1 || cfg.world > 1) && ((Gzc & 1) || ((size_t)g.G * Gzc) % 4 != 0))) {
             set_error("KDYN: %d chunks do not divide the %d local z planes into even parts with G*Gz %% 4 == 0", k, g.Gzr);
             return SMO_ERR_ARG;
         }
@@ -829,16 +835,18 @@ public:
     int init() override {
         const int N = cfg.npts, W = cfg.world;
         if (cfg.batch != 1) { set_error("KDYN: batch must be 1"); return SMO_ERR_ARG; }
+        // Tuned kernels: the transform lengths G = 3N/2 with factors 2, 3, 5 and 7 instantiated below (with_L).  Every other even Npts — the
+        // reference, through FFTW, takes any (FWD_Solve_KDyn.py:362-450, :1029) — runs the run-time-length kernels of kdyn_any.hpp
+        // (SMO_KD_ANY=1 forces them at a tuned size too: how the tests compare the two paths).
         static const int sizes[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 100, 112, 120, 128, 144, 160, 192, 200, 224, 240, 256, 320};
-        if (std::find(std::begin(sizes), std::end(sizes), N) == std::end(sizes)) {
-            // the transform lengths G = 3N/2 are compile-time instantiations (factors 2, 3, 5 and 7); the reference, through FFTW, takes any even Npts
-            set_error("KDYN: npts must be one of 8,12,16,20,24,28,32,36,40,48,56,60,64,72,80,96,100,112,120,128,144,160,192,200,224,240,256,320 (got %d)", N);
-            return SMO_ERR_UNSUPPORTED;
-        }
-        if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0) {
+        if (N < 6 || (N & 1)) { set_error("KDYN: npts must be even and >= 6 (got %d)", N); return SMO_ERR_UNSUPPORTED; }
+        any_size = std::find(std::begin(sizes), std::end(sizes), N) == std::end(sizes);
+        { const char* e = getenv("SMO_KD_ANY"); if (e && atoi(e) == 1) any_size = true; }
+        if ((N / 2) % W != 0 || (3 * N / 2) % W != 0 || (W > 1 && ((3 * N / 2 / W) * (3 * N / 2)) % 4 != 0)) {
             set_error("KDYN: %d slabs do not divide a=%d kx modes and G=%d grid planes", W, N / 2, 3 * N / 2);
             return SMO_ERR_UNSUPPORTED;
         }
+        if (!any_size && ((3 * N / 2) * (3 * N / 2)) % 4 != 0) any_size = true;      // (cannot happen for the sizes above: G is even there)
         g.a = N / 2; g.al = g.a / W; g.ix0 = cfg.rank * g.al; g.m = N - 1; g.kmax = (N - 1) / 2; g.G = 3 * N / 2; g.Gzl = g.Gzr = g.G / W; g.W = W; g.zg0 = 0;
         g.Rm = cfg.param; g.dt = cfg.dt;
         nmode = (size_t)g.al * g.m * g.m;
@@ -849,6 +857,22 @@ public:
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
+        if (any_size) {
+            fuse_next = false;                               // the run-time-length update kernel has no fused next pass
+            plan = any_plan(3 * N / 2);
+            // LDS of one workgroup: 64 KB unless the narrowest tile of the adjoint x pass (3 buffers x 3 transforms) needs more
+            if ((size_t)144 * plan.L > any_lds) {
+                int dev = 0, maxb = 0;
+                SMO_HIP(hipGetDevice(&dev));
+                SMO_HIP(hipDeviceGetAttribute(&maxb, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+                if ((size_t)144 * plan.L > (size_t)maxb) { set_error("KDYN: G = %d needs %zu bytes of LDS per workgroup (device: %d)", plan.L, (size_t)144 * plan.L, maxb); return SMO_ERR_UNSUPPORTED; }
+                any_lds = (size_t)maxb;
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_forward, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_y_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_x_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+            }
+        }
         { const char* e = getenv("SMO_KD_GRAPH"); if (e) graph_mode = atoi(e); }
         { const char* e = getenv("SMO_KD_GRAPH_MAXG"); if (e) graph_max_g = atoi(e); }
         { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
@@ -980,6 +1004,15 @@ public:
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
 
+    // run-time-length path (kdyn_any.hpp): largest tile of `unit` bytes per transform-row multiple that fits the LDS limit
+    bool any_size = false;
+    AnyPlan plan{};
+    size_t any_lds = 65536;
+    int any_tile(size_t bytes_per_unit, std::initializer_list<int> cands) const {
+        for (int c : cands) if ((size_t)c * bytes_per_unit * plan.L <= any_lds) return c;
+        return *(cands.end() - 1);
+    }
+
     int need_buffers() {
         if (!zs || !ys) { set_error("KDYN: slab exchange buffers not set (SMO_KD_SET_BUFFERS)"); return SMO_ERR_STATE; }
         return SMO_OK;
@@ -989,6 +1022,12 @@ public:
         const Geom g = geom(nf);
         zs_ready_fwd = zs_ready_adj = -1;
         cplx* out = zs + (size_t)f * tzc;
+        if (any_size) {
+            const int NBT = any_tile(96, {2, 1}), nwg = (g.al * g.m + NBT - 1) / NBT;
+            ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
+            hipLaunchKernelGGL(kda_z_inverse, dim3(nwg), dim3(256), (size_t)96 * NBT * plan.L, stream, in, out, (const cplx*)d_tw, g, plan, mode, NBT);
+            return SMO_OK;
+        }
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -1005,6 +1044,13 @@ public:
         const Geom q = geom(nf, k);
         if (!inv && ys == zs) zs_ready_fwd = zs_ready_adj = -1;      // one GPU: the y pass writes the buffer the z pass reads
         cplx* ex = ys + (size_t)k * q.cblk + (size_t)f * tzc;
+        if (any_size) {
+            const int ZT = any_tile(32, {8, 4, 2, 1}), nwg = 3 * g.a * ((g.Gzl + ZT - 1) / ZT);
+            ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
+            hipLaunchKernelGGL(kda_y_pass, dim3(nwg), dim3(256), (size_t)32 * ZT * plan.L, stream, inv ? (const cplx*)ex : (const cplx*)ty, inv ? ty : ex,
+                               (const cplx*)d_tw, q, plan, inv ? 1 : 0, ZT);
+            return SMO_OK;
+        }
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -1034,6 +1080,16 @@ public:
         cplx *tA = d_ty + (size_t)k * fldc, *tB = d_ty + fld + (size_t)k * fldc;
         const XSpec sp{inA ? inA : tA, inB ? inB : tB, tA, mode == X_FUSED_ADJ ? d_acc + (size_t)k * fldc : tB};
         auto tiles = [&](int T) { return dim3((unsigned)((plane + T - 1) / T)); };
+        if (any_size) {
+            // the internal U field stays in the flat grid layout [3][G][G][Gzr] (all chunks in one array: Geom::zg0 places the chunk)
+            q.utile = 0;
+            const int nbuf = mode == X_FUSED_ADJ ? 3 : 2, HP = any_tile((size_t)48 * nbuf, {4, 2, 1});
+            const int kc = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
+            ScopedTimer t(timing, kc, stream);
+            hipLaunchKernelGGL(kda_x_pass, tiles(2 * HP), dim3(256), (size_t)48 * nbuf * HP * plan.L, stream, sp, mode == X_FROM_GRID ? vec_in : (const double*)d_U,
+                               to_U ? d_U : vec_out, (const cplx*)d_tw, q, plan, mode, HP);
+            return SMO_OK;
+        }
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
@@ -1059,6 +1115,13 @@ public:
         const Geom g = geom(1);
         const double scale = 1.0 / ((double)g.G * g.G * g.G);
         const int integ = cfg.cost == SMO_COST_INTEGRATED;
+        if (any_size) {
+            const int NBT = any_tile(96, {2, 1}), nwg = (g.al * g.m + NBT - 1) / NBT;
+            ScopedTimer t(timing, mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc), stream);
+            hipLaunchKernelGGL(kda_z_forward, dim3(nwg), dim3(256), (size_t)96 * NBT * plan.L, stream, (const cplx*)zs, out0, state0, snp, (const cplx*)d_tw, g, plan,
+                               mode, NBT, scale, integ);
+            return SMO_OK;
+        }
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;

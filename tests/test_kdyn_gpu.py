@@ -247,9 +247,57 @@ def test_known_answer_single_mode_decay(N):
     dom.drop_contexts()
 
 
+# ---- any even Npts: the run-time-length kernels (csrc/kdyn_any.hpp) ----------------------------------------------------------------
+# The reference builds its Fourier bases for whatever Npts it is handed (FWD_Solve_KDyn.py:362-450).  Sizes without a tuned
+# instantiation: prime factors 11, 13, 37, 53 of G = 3 Npts / 2, and Npts = 2 mod 4, where G is ODD (the last (y,z) line of a plane has
+# no partner in the two-lines-per-transform packing).
+_ANY_SMALL = [(6, 3, 1e-2, True), (10, 3, 1e-2, True), (22, 3, 1e-2, True), (44, 2, 1e-3, True)]      # G = 9, 15, 33, 66
+_ANY_CASES = [(N, n, dt, d, c, a) for (N, n, dt, d) in _ANY_SMALL for (c, a) in _ALL4] + \
+             [(14, 2, 1e-2, False, "Final", "Discrete"), (18, 2, 1e-2, True, "Integrated", "Continuous"), (26, 2, 1e-2, True, "Final", "Continuous"),
+              (52, 1, 1e-3, True, "Integrated", "Discrete"), (74, 1, 1e-3, False, "Final", "Discrete"), (106, 1, 1e-3, True, "Final", "Discrete")]
+
+
+@pytest.mark.parametrize("N,n,dt,dirty,cost,adj", _ANY_CASES)
+def test_any_even_npts_vs_oracle(N, n, dt, dirty, cost, adj):
+    test_forward_adjoint_vs_oracle(N, n, dt, dirty, cost, adj)
+
+
+@pytest.mark.parametrize("N,ckpt", [(16, 1), (24, 1), (16, 3), (40, 1)])
+@pytest.mark.parametrize("cost,adj", [("Final", "Discrete"), ("Integrated", "Continuous")])
+def test_runtime_length_kernels_match_the_tuned_ones(N, ckpt, cost, adj, monkeypatch):
+    """SMO_KD_ANY=1 sends a tuned size through the run-time-length kernels: same J, gradients and snapshots to rounding (different
+    butterfly order, no fusion), with and without checkpoint windows."""
+    n = 7
+    B, U = _fields(3 * N // 2, dirty=True)
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("SMO_KD_ANY", force)
+        dom = kdyn.KDynDomain(N)
+        dom.ckpt = ckpt
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        args = [dom, 1.0, 1e-2, n, n, buf, cost, adj]
+        J = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+        gB, gU = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+        last = None if ckpt != 1 else np.stack([buf[k][:, :, :, -1] for k in ('A_fwd', 'B_fwd', 'C_fwd')])
+        res.append((J, gB, gU, last))
+        dom.drop_contexts()
+    (J0, gB0, gU0, s0), (J1, gB1, gU1, s1) = res
+    assert abs(J1 - J0) <= 1e-12 * abs(J0)
+    assert rel(gB1, gB0) < 1e-11 and rel(gU1, gU0) < 1e-11
+    if s0 is not None:
+        assert rel(s1, s0) < 1e-12
+
+
+@pytest.mark.parametrize("N", [44, 310])
+def test_known_answer_single_mode_decay_any_size(N):
+    """The closed-form CNAB1 answers at sizes only the run-time-length kernels take: G = 66 = 2*3*11, and G = 465 = 3*5*31 — an odd
+    grid whose adjoint x pass needs more than 64 KB of LDS per workgroup (the opt-in above the default limit)."""
+    test_known_answer_single_mode_decay(N)
+
+
 def test_errors():
     with pytest.raises(_capi.SmoError):
-        _capi.Context(_capi.SMO_KDYN, 44, (0., 2 * np.pi), 1e-3, 2, 1.0)      # unsupported size (G = 66 has a factor 11)
+        _capi.Context(_capi.SMO_KDYN, 45, (0., 2 * np.pi), 1e-3, 2, 1.0)      # odd Npts: G = 3 Npts / 2 is not an integer
     ctx = _capi.Context(_capi.SMO_KDYN, 8, (0., 2 * np.pi), 1e-3, 2, 1.0)
     with pytest.raises(_capi.SmoError) as e:
         ctx.adjoint(None)

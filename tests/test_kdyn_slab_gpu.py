@@ -106,6 +106,21 @@ def test_in_library_loop_with_ranks_sharing_one_gpu_matches_oracle(tmp_path, N, 
     _check_vs_oracle(out, N, n, cost, adj)
 
 
+@pytest.mark.parametrize("N,world,cost,adj,keep,chunks,force", [(88, 2, "Final", "Discrete", True, 1, False),
+                                                                 (32, 2, "Integrated", "Continuous", False, 2, True),
+                                                                 (48, 4, "Final", "Discrete", True, 3, True)])
+def test_runtime_length_kernels_with_slabs(tmp_path, monkeypatch, N, world, cost, adj, keep, chunks, force):
+    """The any-size kernels (csrc/kdyn_any.hpp) use the slab-exchange layouts of the tuned ones: Npts = 88 (G = 132 = 4*3*11, no tuned
+    instantiation) on two slabs, and tuned sizes forced through them (SMO_KD_ANY=1) with the chunk pipeline."""
+    import torch.multiprocessing as mp
+    if force:
+        monkeypatch.setenv("SMO_KD_ANY", "1")
+    n = 3
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, n, cost, adj, keep, chunks, out, True), nprocs=world, join=True)
+    _check_vs_oracle(out, N, n, cost, adj)
+
+
 @pytest.mark.parametrize("N,world,cost,adj,ckpt,n,chunks", [(16, 2, "Final", "Discrete", 3, 7, 1), (32, 2, "Integrated", "Continuous", 2, 5, 2),
                                                             (16, 4, "Final", "Discrete", 0, 4, 1)])
 def test_windowed_checkpoints_with_slabs(tmp_path, N, world, cost, adj, ckpt, n, chunks):

@@ -102,9 +102,10 @@ def test_taylor_sh23():
     assert _slopes_ok(AA), AA
 
 
+@pytest.mark.parametrize("N", [12, 10, 22])      # G = 18; 15 and 33: odd grids (Npts = 2 mod 4), which only the device's run-time-length kernels take
 @pytest.mark.parametrize("cost", ["Final", "Integrated"])
-def test_taylor_kdyn(cost):
-    k = KDynOracle(12, Rm=1., dt=1e-2, N_ITERS=12, Cost_function=cost)
+def test_taylor_kdyn(cost, N):
+    k = KDynOracle(N, Rm=1., dt=1e-2, N_ITERS=12 if N == 12 else 6, Cost_function=cost)
     B = synthetic_field(k.G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * k.G ** 3)   # not div-free, mean != 0
     U, dB, dU = (synthetic_field(k.G, s) for s in (2, 3, 4))
     AA = taylor_table([B, U], [dB, dU], k.forward, k.adjoint, k.inner, epsilon=1e-3)
