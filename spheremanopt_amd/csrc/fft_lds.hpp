@@ -314,4 +314,76 @@ __device__ __forceinline__ void fft_inplace_head(cplx* buf, IX ix, TW tw, int ti
     InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST>::run(buf, ix, tid, tw);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Run-time-length variant: the transform length is a kernel argument, the radices are the prime factors of L found on the host
+// (any_plan), and every stage is evaluated one OUTPUT per thread as a direct sum over its radix — any length works (a prime factor p
+// costs p multiply-adds per point), at a multiple of the cost of the compile-time chains above.  Used where a size has no tuned
+// instantiation: csrc/kdyn_any.hpp (any even Npts of the 3-D case), the SH23 any-length kernels.
+// ---------------------------------------------------------------------------------------------------------
+struct AnyPlan {
+    int L;            // transform length
+    int nst;          // Stockham stages
+    int r[20];        // their radices (product = L)
+};
+
+inline AnyPlan any_plan(int L) {
+    AnyPlan p{};
+    p.L = L;
+    int n = L;
+    while (n % 4 == 0) { p.r[p.nst++] = 4; n /= 4; }
+    if (n % 2 == 0) { p.r[p.nst++] = 2; n /= 2; }
+    for (int f = 3; n > 1; f += 2)
+        while (n % f == 0) { p.r[p.nst++] = f; n /= f; }
+    return p;
+}
+
+// NB transforms of length L, element (b, pos) at b * L + pos, in `src`; ping-pong with `dst`; returns the buffer that holds the result.
+// Stage invariant n * s == L (see the top of this file):  y[q + s (R p + j)] = w_n^{p j} sum_k x[q + s (p + k n/R)] w_R^{j k}.
+// tw[k] = exp(-2 pi i k / L), in the LDS like the buffers (the callers copy it there: one table load per multiply-add from global
+// memory instead made the 3-D passes 1.5x slower).  Radices 2 and 4 need no table for w_R (+-1, +-i).  Ends with a barrier.
+template <bool INV>
+__device__ __forceinline__ cplx* any_fft(cplx* src, cplx* dst, const cplx* tw, const AnyPlan& pl, int NB, int tid, int nthr) {
+    const int L = pl.L;
+    int n = L, s = 1;
+    for (int st = 0; st < pl.nst; ++st) {
+        const int R = pl.r[st], M = n / R, wstep = L / R;
+        for (int t = tid; t < NB * L; t += nthr) {
+            const int b = t / L, o = t - b * L;
+            const int q = o % s, rj = o / s, j = rj % R, p = rj / R;
+            const cplx* x = src + (size_t)b * L + q + s * p;
+            const int xs = s * M;
+            cplx acc;
+            if (R == 4) {                               // forward: sum_k x_k (-i)^{j k}; inverse: (+i)^{j k}
+                const cplx x0 = x[0], x1 = x[xs], x2 = x[2 * xs], x3 = x[3 * xs];
+                const cplx e = (j & 1) ? x0 - x2 : x0 + x2, d = (j & 1) ? x1 - x3 : x1 + x3;
+                if (j == 0) acc = e + d;
+                else if (j == 2) acc = e - d;
+                else acc = ((j == 1) != INV) ? e + mul_mi(d) : e + mul_i(d);
+            } else if (R == 2) {
+                acc = j ? x[0] - x[xs] : x[0] + x[xs];
+            } else {
+                acc = x[0];
+                int e = 0;                              // (j k) mod R
+                for (int k = 1; k < R; ++k) {
+                    e += j; if (e >= R) e -= R;
+                    const cplx w = tw[e * wstep], v = x[k * xs];
+                    acc = acc + (INV ? mul_conj(v, w) : v * w);
+                }
+            }
+            if (M > 1 && j) { const cplx w = tw[p * s * j]; acc = INV ? mul_conj(acc, w) : acc * w; }
+            dst[t] = acc;
+        }
+        __syncthreads();
+        cplx* sw = src; src = dst; dst = sw;
+        n = M; s *= R;
+    }
+    return src;
+}
+
+// copy the twiddle table into the LDS (no barrier: the caller's next one covers it)
+__device__ __forceinline__ void any_load_tw(cplx* tw_lds, const cplx* __restrict__ tw_g, int L, int tid, int nthr) {
+    for (int i = tid; i < L; i += nthr) tw_lds[i] = tw_g[i];
+}
+
 }  // namespace smo

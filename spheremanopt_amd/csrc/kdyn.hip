@@ -860,18 +860,7 @@ public:
         if (any_size) {
             fuse_next = false;                               // the run-time-length update kernel has no fused next pass
             plan = any_plan(3 * N / 2);
-            // LDS of one workgroup: 64 KB unless the narrowest tile of the adjoint x pass (3 buffers x 3 transforms) needs more
-            if ((size_t)144 * plan.L > any_lds) {
-                int dev = 0, maxb = 0;
-                SMO_HIP(hipGetDevice(&dev));
-                SMO_HIP(hipDeviceGetAttribute(&maxb, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-                if ((size_t)144 * plan.L > (size_t)maxb) { set_error("KDYN: G = %d needs %zu bytes of LDS per workgroup (device: %d)", plan.L, (size_t)144 * plan.L, maxb); return SMO_ERR_UNSUPPORTED; }
-                any_lds = (size_t)maxb;
-                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
-                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_forward, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
-                SMO_HIP(hipFuncSetAttribute((const void*)kda_y_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
-                SMO_HIP(hipFuncSetAttribute((const void*)kda_x_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
-            }
+            if (const char* e = getenv("SMO_KD_ANY_NT")) { const int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) any_nt = v; }
         }
         { const char* e = getenv("SMO_KD_GRAPH"); if (e) graph_mode = atoi(e); }
         { const char* e = getenv("SMO_KD_GRAPH_MAXG"); if (e) graph_max_g = atoi(e); }
@@ -886,6 +875,20 @@ public:
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
         SMO_TRY(base_init());
+        if (any_size) {
+            // LDS of one workgroup: 64 KB unless the narrowest tile of the adjoint x pass (3 buffers x 3 transforms + the twiddle table) needs more
+            if ((size_t)160 * plan.L > any_lds) {
+                int dev = 0, maxb = 0;
+                SMO_HIP(hipGetDevice(&dev));
+                SMO_HIP(hipDeviceGetAttribute(&maxb, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+                if ((size_t)160 * plan.L > (size_t)maxb) { set_error("KDYN: G = %d needs %zu bytes of LDS per workgroup (device: %d)", plan.L, (size_t)160 * plan.L, maxb); return SMO_ERR_UNSUPPORTED; }
+                any_lds = (size_t)maxb;
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_z_forward, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_y_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+                SMO_HIP(hipFuncSetAttribute((const void*)kda_x_pass, hipFuncAttributeMaxDynamicSharedMemorySize, maxb));
+            }
+        }
         ck = cfg.ckpt;
         if (ck < 0) { set_error("KDYN: ckpt=%d", ck); return SMO_ERR_ARG; }
         if (ck == 0) {                                       // smallest interval that fits the free HBM (keep 8 GB + work buffers spare)
@@ -1008,8 +1011,9 @@ public:
     bool any_size = false;
     AnyPlan plan{};
     size_t any_lds = 65536;
+    int any_nt = 512;                            // threads per workgroup of the any-size kernels (SMO_KD_ANY_NT)
     int any_tile(size_t bytes_per_unit, std::initializer_list<int> cands) const {
-        for (int c : cands) if ((size_t)c * bytes_per_unit * plan.L <= any_lds) return c;
+        for (int c : cands) if (((size_t)c * bytes_per_unit + 16) * plan.L <= any_lds) return c;      // + the twiddle table
         return *(cands.end() - 1);
     }
 
@@ -1025,7 +1029,7 @@ public:
         if (any_size) {
             const int NBT = any_tile(96, {2, 1}), nwg = (g.al * g.m + NBT - 1) / NBT;
             ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
-            hipLaunchKernelGGL(kda_z_inverse, dim3(nwg), dim3(256), (size_t)96 * NBT * plan.L, stream, in, out, (const cplx*)d_tw, g, plan, mode, NBT);
+            hipLaunchKernelGGL(kda_z_inverse, dim3(nwg), dim3(any_nt), ((size_t)96 * NBT + 16) * plan.L, stream, in, out, (const cplx*)d_tw, g, plan, mode, NBT);
             return SMO_OK;
         }
         return with_L([&](auto l) {
@@ -1047,7 +1051,7 @@ public:
         if (any_size) {
             const int ZT = any_tile(32, {8, 4, 2, 1}), nwg = 3 * g.a * ((g.Gzl + ZT - 1) / ZT);
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
-            hipLaunchKernelGGL(kda_y_pass, dim3(nwg), dim3(256), (size_t)32 * ZT * plan.L, stream, inv ? (const cplx*)ex : (const cplx*)ty, inv ? ty : ex,
+            hipLaunchKernelGGL(kda_y_pass, dim3(nwg), dim3(any_nt), ((size_t)32 * ZT + 16) * plan.L, stream, inv ? (const cplx*)ex : (const cplx*)ty, inv ? ty : ex,
                                (const cplx*)d_tw, q, plan, inv ? 1 : 0, ZT);
             return SMO_OK;
         }
@@ -1086,7 +1090,7 @@ public:
             const int nbuf = mode == X_FUSED_ADJ ? 3 : 2, HP = any_tile((size_t)48 * nbuf, {4, 2, 1});
             const int kc = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
             ScopedTimer t(timing, kc, stream);
-            hipLaunchKernelGGL(kda_x_pass, tiles(2 * HP), dim3(256), (size_t)48 * nbuf * HP * plan.L, stream, sp, mode == X_FROM_GRID ? vec_in : (const double*)d_U,
+            hipLaunchKernelGGL(kda_x_pass, tiles(2 * HP), dim3(any_nt), ((size_t)48 * nbuf * HP + 16) * plan.L, stream, sp, mode == X_FROM_GRID ? vec_in : (const double*)d_U,
                                to_U ? d_U : vec_out, (const cplx*)d_tw, q, plan, mode, HP);
             return SMO_OK;
         }
@@ -1118,7 +1122,7 @@ public:
         if (any_size) {
             const int NBT = any_tile(96, {2, 1}), nwg = (g.al * g.m + NBT - 1) / NBT;
             ScopedTimer t(timing, mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc), stream);
-            hipLaunchKernelGGL(kda_z_forward, dim3(nwg), dim3(256), (size_t)96 * NBT * plan.L, stream, (const cplx*)zs, out0, state0, snp, (const cplx*)d_tw, g, plan,
+            hipLaunchKernelGGL(kda_z_forward, dim3(nwg), dim3(any_nt), ((size_t)96 * NBT + 16) * plan.L, stream, (const cplx*)zs, out0, state0, snp, (const cplx*)d_tw, g, plan,
                                mode, NBT, scale, integ);
             return SMO_OK;
         }

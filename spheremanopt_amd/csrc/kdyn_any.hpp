@@ -11,59 +11,15 @@
 // Slower than the tuned path by design (short runs, LDS ping-pong, no fusion); results agree with the oracle like the tuned kernels' do.
 #pragma once
 
-struct AnyPlan {
-    int L;            // transform length
-    int nst;          // Stockham stages
-    int r[20];        // their radices (product = L)
-};
-
-inline AnyPlan any_plan(int L) {
-    AnyPlan p{};
-    p.L = L;
-    int n = L;
-    while (n % 4 == 0) { p.r[p.nst++] = 4; n /= 4; }
-    if (n % 2 == 0) { p.r[p.nst++] = 2; n /= 2; }
-    for (int f = 3; n > 1; f += 2)
-        while (n % f == 0) { p.r[p.nst++] = f; n /= f; }
-    return p;
-}
-
-// NB transforms of length L, element (b, pos) at b * L + pos, in `src`; ping-pong with `dst`; returns the buffer that holds the result.
-// Stage invariant n * s == L (fft_lds.hpp):  y[q + s (R p + j)] = w_n^{p j} sum_k x[q + s (p + k n/R)] w_R^{j k}.
-// tw[k] = exp(-2 pi i k / L) in global memory (L2-resident).  Ends with a barrier.
-template <bool INV>
-__device__ cplx* any_fft(cplx* src, cplx* dst, const cplx* __restrict__ tw, const AnyPlan& pl, int NB, int tid, int nthr) {
-    const int L = pl.L;
-    int n = L, s = 1;
-    for (int st = 0; st < pl.nst; ++st) {
-        const int R = pl.r[st], M = n / R, wstep = L / R;
-        for (int t = tid; t < NB * L; t += nthr) {
-            const int b = t / L, o = t - b * L;
-            const int q = o % s, rj = o / s, j = rj % R, p = rj / R;
-            const cplx* x = src + (size_t)b * L + q + s * p;
-            cplx acc = x[0];
-            int e = 0;                                  // (j k) mod R
-            for (int k = 1; k < R; ++k) {
-                e += j; if (e >= R) e -= R;
-                const cplx w = tw[e * wstep], v = x[s * k * M];
-                acc = acc + (INV ? mul_conj(v, w) : v * w);
-            }
-            if (M > 1 && j) { const cplx w = tw[p * s * j]; acc = INV ? mul_conj(acc, w) : acc * w; }
-            dst[t] = acc;
-        }
-        __syncthreads();
-        cplx* sw = src; src = dst; dst = sw;
-        n = M; s *= R;
-    }
-    return src;
-}
+// (AnyPlan / any_plan / any_fft: the run-time-length Stockham chain, fft_lds.hpp)
 
 // ---- z pass, inverse: coefficients -> Tz (kd_z_inverse) -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kda_z_inverse(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw, Geom g,
+__global__ __launch_bounds__(1024) void kda_z_inverse(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw, Geom g,
                                                      AnyPlan pl, int mode, int NBT) {
     extern __shared__ cplx any_lds[];
     const int L = pl.L, NB = 3 * NBT, tid = threadIdx.x, NT = blockDim.x;
-    cplx *A = any_lds, *B = any_lds + (size_t)NB * L;
+    cplx *A = any_lds, *B = any_lds + (size_t)NB * L, *tws = any_lds + (size_t)2 * NB * L;
+    any_load_tw(tws, tw, L, tid, NT);
     const int nrt = g.al * g.m, rt0 = blockIdx.x * NBT;
     const size_t cs = (size_t)nrt * g.m;
     for (int t = tid; t < NB * L; t += NT) {                       // raw rows, zero-padded to L
@@ -90,7 +46,7 @@ __global__ __launch_bounds__(256) void kda_z_inverse(const cplx* __restrict__ in
         A[t] = v;
     }
     __syncthreads();
-    const cplx* R = any_fft<true>(A, B, tw, pl, NB, tid, NT);
+    const cplx* R = any_fft<true>(A, B, tws, pl, NB, tid, NT);
     for (int t = tid; t < NB * L; t += NT) {
         const int b = t / L, pos = t - b * L, tt = b / 3, c = b - 3 * tt, rt = rt0 + tt;
         if (rt < nrt) out[zs_off(c, rt, pos, g)] = R[t];
@@ -98,12 +54,13 @@ __global__ __launch_bounds__(256) void kda_z_inverse(const cplx* __restrict__ in
 }
 
 // ---- z pass, forward: Tz -> coefficients, with the per-mode step (kd_z_forward; no fused next pass) --------------------------
-__global__ __launch_bounds__(256) void kda_z_forward(const cplx* __restrict__ inA, cplx* out0, const cplx* state0 /* may alias out0 */,
+__global__ __launch_bounds__(1024) void kda_z_forward(const cplx* __restrict__ inA, cplx* out0, const cplx* state0 /* may alias out0 */,
                                                      const cplx* __restrict__ snap, const cplx* __restrict__ tw, Geom g, AnyPlan pl, int mode,
                                                      int NBT, double scale, int integrated) {
     extern __shared__ cplx any_lds[];
     const int L = pl.L, NB = 3 * NBT, tid = threadIdx.x, NT = blockDim.x;
-    cplx *A = any_lds, *B = any_lds + (size_t)NB * L;
+    cplx *A = any_lds, *B = any_lds + (size_t)NB * L, *tws = any_lds + (size_t)2 * NB * L;
+    any_load_tw(tws, tw, L, tid, NT);
     const int nrt = g.al * g.m, rt0 = blockIdx.x * NBT;
     const size_t cs = (size_t)nrt * g.m;
     for (int t = tid; t < NB * L; t += NT) {
@@ -111,7 +68,7 @@ __global__ __launch_bounds__(256) void kda_z_forward(const cplx* __restrict__ in
         A[t] = (rt < nrt) ? inA[zs_off(c, rt, pos, g)] : mk(0, 0);
     }
     __syncthreads();
-    const cplx* R = any_fft<false>(A, B, tw, pl, NB, tid, NT);
+    const cplx* R = any_fft<false>(A, B, tws, pl, NB, tid, NT);
     for (int t = tid; t < NBT * g.m; t += NT) {                      // per retained mode: thread <-> (tt, iz)
         const int tt = t / g.m, iz = t - tt * g.m, rt = rt0 + tt;
         if (rt >= nrt) continue;
@@ -156,11 +113,12 @@ __global__ __launch_bounds__(256) void kda_z_forward(const cplx* __restrict__ in
 }
 
 // ---- y pass: Tz (y-side exchange layout) <-> Ty; ZT consecutive z columns per workgroup (kd_y_pass) --------------------------
-__global__ __launch_bounds__(256) void kda_y_pass(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw, Geom g,
+__global__ __launch_bounds__(1024) void kda_y_pass(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw, Geom g,
                                                   AnyPlan pl, int inv, int ZT) {
     extern __shared__ cplx any_lds[];
     const int L = pl.L, tid = threadIdx.x, NT = blockDim.x;
-    cplx *A = any_lds, *B = any_lds + (size_t)ZT * L;
+    cplx *A = any_lds, *B = any_lds + (size_t)ZT * L, *tws = any_lds + (size_t)2 * ZT * L;
+    any_load_tw(tws, tw, L, tid, NT);
     const int ntile = (g.Gzl + ZT - 1) / ZT;
     const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * a + kx
     const int c = o / g.a, kx = o - c * g.a;
@@ -175,7 +133,7 @@ __global__ __launch_bounds__(256) void kda_y_pass(const cplx* __restrict__ in, c
         A[b * L + pos] = v;
     }
     __syncthreads();
-    const cplx* R = inv ? any_fft<true>(A, B, tw, pl, ZT, tid, NT) : any_fft<false>(A, B, tw, pl, ZT, tid, NT);
+    const cplx* R = inv ? any_fft<true>(A, B, tws, pl, ZT, tid, NT) : any_fft<false>(A, B, tws, pl, ZT, tid, NT);
     for (int t = tid; t < ZT * L; t += NT) {
         const int pos = t / ZT, b = t - pos * ZT;
         if (z0 + b >= g.Gzl) continue;
@@ -187,12 +145,14 @@ __global__ __launch_bounds__(256) void kda_y_pass(const cplx* __restrict__ in, c
 // ---- x pass: Hermitian half spectrum <-> real lines, two lines per complex transform, T = 2 HP flat (y,z) points per workgroup
 // (kd_x_pass).  Modes as in kdyn.hip; the fused adjoint pass sends its two field groups through the buffers one after the other
 // (omega's grid values stay in the third buffer).  The internal U field is kept in the flat grid layout here (Geom::utile = 0).
-__global__ __launch_bounds__(256) void kda_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut, const cplx* __restrict__ tw, Geom g,
+__global__ __launch_bounds__(1024) void kda_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut, const cplx* __restrict__ tw, Geom g,
                                                   AnyPlan pl, int mode, int HP) {
     extern __shared__ cplx any_lds[];
     const int L = pl.L, NB = 3 * HP, tid = threadIdx.x, NT = blockDim.x;
     const size_t plane = (size_t)g.G * g.Gzl, i0 = (size_t)blockIdx.x * 2 * HP;
-    cplx* P[3] = {any_lds, any_lds + (size_t)NB * L, any_lds + (size_t)2 * NB * L};
+    cplx* P[3] = {any_lds, any_lds + (size_t)NB * L, any_lds + (size_t)2 * NB * L};      // (the third only in the adjoint pass)
+    cplx* tws = any_lds + (size_t)(mode == X_FUSED_ADJ ? 3 : 2) * NB * L;
+    any_load_tw(tws, tw, L, tid, NT);
     // b = c * HP + p; the second line of the last pair is absent when the plane has an odd number of points
     auto ok1 = [&](int p) { return i0 + 2 * p < plane; };
     auto ok2 = [&](int p) { return i0 + 2 * p + 1 < plane; };
@@ -256,11 +216,11 @@ __global__ __launch_bounds__(256) void kda_x_pass(XSpec sp, const double* __rest
             P[0][(size_t)(c * HP + p) * L + x] = v;
         }
         __syncthreads();
-        split_store(any_fft<false>(P[0], P[1], tw, pl, NB, tid, NT), sp.outA, false);
+        split_store(any_fft<false>(P[0], P[1], tws, pl, NB, tid, NT), sp.outA, false);
         return;
     }
     load_spec(sp.inA, P[0]);
-    cplx* W = any_fft<true>(P[0], P[1], tw, pl, NB, tid, NT);      // field group A on the grid
+    cplx* W = any_fft<true>(P[0], P[1], tws, pl, NB, tid, NT);      // field group A on the grid
     cplx* F = (W == P[0]) ? P[1] : P[0];                            // free buffer
     if (mode == X_TO_GRID) {
         for (int t = tid; t < NB * L; t += NT) {
@@ -275,16 +235,16 @@ __global__ __launch_bounds__(256) void kda_x_pass(XSpec sp, const double* __rest
     }
     if (mode == X_FUSED_FWD) {                                      // EMF = U x B
         cross(nullptr, W, F, true, false);
-        split_store(any_fft<false>(F, W, tw, pl, NB, tid, NT), sp.outA, false);
+        split_store(any_fft<false>(F, W, tws, pl, NB, tid, NT), sp.outA, false);
         return;
     }
     // adjoint: F1 = omega x U -> out A;  F2' = omega x B_f -> added to the running sum out B
     cross(W, nullptr, F, false, true);
-    split_store(any_fft<false>(F, P[2], tw, pl, NB, tid, NT), sp.outA, false);
+    split_store(any_fft<false>(F, P[2], tws, pl, NB, tid, NT), sp.outA, false);
     __syncthreads();
     load_spec(sp.inB, F);
-    cplx* Bf = any_fft<true>(F, P[2], tw, pl, NB, tid, NT);
+    cplx* Bf = any_fft<true>(F, P[2], tws, pl, NB, tid, NT);
     cplx* F2 = (Bf == F) ? P[2] : F;
     cross(W, Bf, F2, false, false);
-    split_store(any_fft<false>(F2, Bf, tw, pl, NB, tid, NT), sp.outB, true);
+    split_store(any_fft<false>(F2, Bf, tws, pl, NB, tid, NT), sp.outB, true);
 }

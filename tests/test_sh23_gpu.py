@@ -45,6 +45,33 @@ def test_forward_adjoint_vs_oracle(Npts, dt, n, adj):
     assert abs(sh23.Inner_Prod(X, X, dom) - 0.0725) < 1e-12
 
 
+# any Npts: the run-time-length kernels (csrc/sh23.hip, sh23_*_any).  Lengths without an instantiation — prime factors 11, 13, 37, 127, odd
+# Npts, a prime Npts — and, above 819, the opt-in beyond 64 KB of LDS per workgroup.
+@pytest.mark.parametrize("Npts,dt,n", [(18, 0.1, 10), (21, 0.1, 12), (22, 0.1, 10), (50, 0.1, 40), (97, 0.1, 20), (250, 0.1, 60), (254, 0.1, 30),
+                                       (333, 0.05, 25), (1000, 0.02, 15), (1100, 0.02, 8)])
+@pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
+def test_any_npts_vs_oracle(Npts, dt, n, adj):
+    test_forward_adjoint_vs_oracle(Npts, dt, n, adj)
+
+
+@pytest.mark.parametrize("Npts", [64, 96, 256])
+@pytest.mark.parametrize("adj", ["Discrete", "Continuous"])
+def test_any_length_kernels_match_the_instantiated_ones(Npts, adj, monkeypatch):
+    """SMO_SH_ANY=1 sends an instantiated length through the any-length kernels: same J, gradient and snapshots to rounding."""
+    n, dt = 80, 0.1
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("SMO_SH_ANY", force)
+        dom, X = sh23.Generate_IC(0.0725, Npts=Npts, seed=42)
+        buf = sh23.GEN_BUFFER(dom, n)
+        args = [dom, dt, n, n, buf, None, adj]
+        J = sh23.FWD_Solve_IVP_Lin([X], *args)
+        g = sh23.ADJ_Solve_IVP_Lin([X], *args)[0]
+        res.append((J, g, np.array(buf['A_fwd'][:, -1])))
+    (J0, g0, s0), (J1, g1, s1) = res
+    assert abs(J1 - J0) <= 1e-12 * abs(J0) and rel(g1, g0) < 1e-11 and rel(s1, s0) < 1e-12
+
+
 def test_config2_against_committed_oracle_output():
     """BASELINE config 2: Npts=256, T=50, dt=0.1 (500 steps), seed-42 synthetic IC."""
     gold = np.load(os.path.join(GOLDEN, "oracle_sh23_c2.npz"))
@@ -88,8 +115,9 @@ def test_known_answer_linear_growth():
     assert abs(abs(buf['A_fwd'][m, n]) - 0.5 * eps * r ** n) < 1e-7 * eps
 
 
-def test_batched_problems_are_independent():
-    Npts, dt, n, B = 64, 0.1, 30, 5
+@pytest.mark.parametrize("Npts", [64, 50])      # 50: no instantiation, the any-length kernels
+def test_batched_problems_are_independent(Npts):
+    dt, n, B = 0.1, 30, 5
     dom = sh23.SH23Domain(Npts)
     Xs = np.stack([sh23.Generate_IC(0.05 + 0.01 * b, Npts=Npts, seed=b)[1] for b in range(B)])
     ctx = dom.context(dt, n, batch=B)
@@ -112,7 +140,7 @@ def test_adjoint_requires_forward_and_errors_are_loud():
     with pytest.raises(ValueError):
         ctx.forward([np.zeros(7)])
     with pytest.raises(_capi.SmoError):
-        _capi.Context(_capi.SMO_SH23, 100, (0., 1.), 0.1, 5, -0.3)        # not a power of two
+        _capi.Context(_capi.SMO_SH23, 3, (0., 1.), 0.1, 5, -0.3)          # fewer than 4 points
 
 
 def test_optimiser_runs_on_device_callbacks(in_tmp_cwd):
