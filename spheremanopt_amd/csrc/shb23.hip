@@ -193,6 +193,57 @@ __device__ __forceinline__ void gemv_cols(const double* __restrict__ M, const do
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Any N (run-time length, NH = 0 in the templates below): the reference's Chebyshev basis takes whatever N it is handed
+// (FWD_Solve_SHB23.py:196-217).  DCT-II / DCT-III through ONE complex transform of the FULL length N (Makhoul's N-point form), on the
+// run-time-length Stockham chain of fft_lds.hpp — no half-length packing, so odd N works too; tables of N entries.
+// ---------------------------------------------------------------------------------------------------------
+template <> struct DctWork<0> {
+    cplx *P, *T, *tw, *tw4;       // LDS: sequence, ping-pong partner, exp(-2 pi i k / N), exp(-i pi k / (2N)), k < N
+    int N;
+    AnyPlan pl;
+};
+// y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N)) = 2 Re(e^{-i pi k/(2N)} V_k),  V = F_N v,  v[j] = x[2j], v[N-1-j] = x[2j+1]
+template <> __device__ void dct2<0>(DctWork<0>& w, const double* x, double* y, int tid) {
+    const int N = w.N;
+    for (int n = tid; n < N; n += NT) { const int j = (n & 1) ? N - 1 - (n >> 1) : (n >> 1); w.P[j] = mk(x[n], 0.0); }
+    __syncthreads();
+    const cplx* V = any_fft<false>(w.P, w.T, w.tw, w.pl, 1, tid, NT);
+    for (int k = tid; k < N; k += NT) { const cplx t = V[k] * w.tw4[k]; y[k] = 2.0 * t.re; }
+    __syncthreads();
+}
+// y[n] = x[0] + 2 sum_{k>=1} x[k] cos(pi k (2n+1) / (2N)):  v = Re F_N^-1[c_k x_k e^{+i pi k/(2N)}] (c_0 = 1, else 2), y[2j] = v[j], y[2j+1] = v[N-1-j]
+template <> __device__ void dct3<0>(DctWork<0>& w, const double* x, double* y, int tid) {
+    const int N = w.N;
+    for (int k = tid; k < N; k += NT) { const double a = (k == 0) ? x[0] : 2.0 * x[k]; const cplx t = w.tw4[k]; w.P[k] = mk(a * t.re, -a * t.im); }
+    __syncthreads();
+    const cplx* v = any_fft<true>(w.P, w.T, w.tw, w.pl, 1, tid, NT);
+    for (int m = tid; m < N; m += NT) { const int j = (m & 1) ? N - 1 - (m >> 1) : (m >> 1); y[m] = v[j].re; }
+    __syncthreads();
+}
+// out[n] = sum_j M[j][n] v[j] for any N <= NT: thread <-> (column group, n), consecutive lanes read consecutive n
+__device__ __forceinline__ void gemv_any(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
+    const int ngrp = NT / N, cols = (N + ngrp - 1) / ngrp;
+    const int jg = tid / N, n = tid - jg * N;
+    if (jg < ngrp) {
+        double a = 0.0;
+        const int j1 = min(N, (jg + 1) * cols);
+        for (int j = jg * cols; j < j1; ++j) a += M[(size_t)j * N + n] * v[j];
+        part[jg * N + n] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += NT) {
+        double acc = 0.0;
+        for (int q = 0; q < ngrp; ++q) acc += part[q * N + i];
+        out[i] = acc;
+    }
+    __syncthreads();
+}
+template <int NH> __device__ __forceinline__ void shb_gemv(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
+    if constexpr (NH != 0) gemv_cols(M, v, out, part, N, tid);
+    else gemv_any(M, v, out, part, N, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Cluster mode (latency): KC workgroups, one per CU, co-operate on ONE problem.  Member k keeps rows [k*R, (k+1)*R) of the
 // operator resident in its LDS (N = 512: 32 members x 16 rows x 4 KB = 64 KB each) so a step no longer streams 2 MB from L2
 // through one CU; every member redundantly runs the (cheap) transforms, computes its R outputs, and the members all-gather
@@ -274,6 +325,31 @@ template <int NH> __device__ void load_tables(ShbShared<NH>& s, const cplx* tw_g
     __syncthreads();
 }
 
+// any N: the same work area with run-time extents — a struct of LDS pointers instead of an LDS struct (one workgroup per problem only)
+template <> struct ShbShared<0> {
+    DctWork<0> w;
+    double *c, *g, *r, *t, *W, *part, *red;
+    int flag;                                      // (cluster mode only; never used here)
+};
+inline size_t shb_any_lds(int N) { const int Ne = (N + 1) & ~1; return (size_t)4 * N * sizeof(cplx) + ((size_t)5 * Ne + 2 * NT + NT / 64) * sizeof(double); }
+template <int NH> struct ShbRef {
+    using type = ShbShared<NH>&;
+    static __device__ __forceinline__ type get(unsigned char* smem, int, const AnyPlan&) { return *reinterpret_cast<ShbShared<NH>*>(smem); }
+};
+template <> struct ShbRef<0> {
+    using type = ShbShared<0>;
+    static __device__ __forceinline__ type get(unsigned char* smem, int N, const AnyPlan& pl) {
+        cplx* z = reinterpret_cast<cplx*>(smem);
+        double* d = reinterpret_cast<double*>(z + (size_t)4 * N);
+        const int Ne = (N + 1) & ~1;
+        return ShbShared<0>{DctWork<0>{z, z + N, z + 2 * N, z + 3 * N, N, pl}, d, d + Ne, d + 2 * Ne, d + 3 * Ne, d + 4 * Ne, d + 5 * Ne, d + 5 * Ne + 2 * NT, 0};
+    }
+};
+template <> __device__ void load_tables<0>(ShbShared<0>& s, const cplx* tw_g, const cplx*, const cplx* tw4_g, const double* W_g, int tid) {
+    for (int i = tid; i < s.w.N; i += NT) { s.w.tw[i] = tw_g[i]; s.w.tw4[i] = tw4_g[i]; s.W[i] = W_g[i]; }
+    __syncthreads();
+}
+
 // forward: J = -dt * sum_{n=0}^{N_ITERS} <g_n, g_n>_W ; stack[n] = g_n (grid states)
 template <int NH>
 __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restrict__ X, double* __restrict__ stack, double* __restrict__ Jout,
@@ -281,12 +357,12 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
                                                          const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
                                                          const cplx* __restrict__ tw4_g, double dt, double inv_Lz, int n_iters,
                                                          int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
-                                                         unsigned* cl_err, int Nc, int cnts) {
+                                                         unsigned* cl_err, int Nc, int cnts, int n_rt, AnyPlan pl) {
     // N = grid / DCT length; Nc = number of Chebyshev modes the operator acts on (Nc = N for the "Discrete" path; Nc = N/2 for the
     // "Continuous" path: dealias-2 grid, coefficients beyond Nc stay zero, the snapshot stack holds coefficients instead of grid states)
-    constexpr int N = 2 * NH;
+    const int N = NH ? 2 * NH : n_rt;             // NH = 0: run-time length (any N)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    typename ShbRef<NH>::type s = ShbRef<NH>::get(smem, N, pl);
     const int tid = threadIdx.x;
     const size_t prob = blockIdx.x / KC;
     const int NS = cnts ? Nc : N;                    // doubles per snapshot
@@ -327,12 +403,12 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
         __syncthreads();
         dct2(s.w, s.t, s.r, tid);                      // h = Z T[...]
         for (int k = tid; k < N; k += NT) {
-            const double h = (k < NH) ? s.r[k] * (((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N) : 0.0;
+            const double h = (k < N / 2) ? s.r[k] * (((k == 0) ? 0.5 : ((k & 1) ? -1.0 : 1.0)) / N) : 0.0;
             s.r[k] = h + s.c[k] * inv_dt;
         }
         __syncthreads();
         if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, Nc, tid)) return; }
-        else gemv_cols(ST, s.r, s.c, s.part, Nc, tid); // c = S r  (entries beyond Nc stay zero)
+        else shb_gemv<NH>(ST, s.r, s.c, s.part, Nc, tid); // c = S r  (entries beyond Nc stay zero)
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) s.red[tid >> 6] = acc;
@@ -350,10 +426,10 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
                                                          const double* __restrict__ W_g, const cplx* __restrict__ tw_g,
                                                          const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters,
                                                          int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
-                                                         unsigned* cl_err) {
-    constexpr int N = 2 * NH;
+                                                         unsigned* cl_err, int n_rt, AnyPlan pl) {
+    const int N = NH ? 2 * NH : n_rt;             // NH = 0: run-time length (any N)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    typename ShbRef<NH>::type s = ShbRef<NH>::get(smem, N, pl);
     const int tid = threadIdx.x;
     const size_t prob = blockIdx.x / KC;
     stack += prob * (size_t)(n_iters + 1) * N;
@@ -378,7 +454,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
     for (int it = 0; it < n_iters; ++it) {
         const double bi = (tid < N) ? stack[(size_t)(n_iters - 1 - it) * N + tid] : 0.0;     // prefetch b under the GEMV
         if (KC > 1) { if (!cluster_gemv(cl, s.c, s.r, N, tid)) return; }
-        else gemv_cols(Sm, s.c, s.r, s.part, N, tid);              // r = S^T p
+        else shb_gemv<NH>(Sm, s.c, s.r, s.part, N, tid);              // r = S^T p
         for (int k = tid; k < N; k += NT) s.t[k] = ((k & 1) ? -1.0 : 1.0) * s.r[k];          // T^T r = DCT3(s o r) / N
         __syncthreads();
         dct3(s.w, s.t, s.g, tid);
@@ -402,10 +478,10 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
                                                               const double* __restrict__ W_g, const cplx* __restrict__ tw_g,
                                                               const cplx* __restrict__ twN_g, const cplx* __restrict__ tw4_g, double dt, int n_iters,
                                                               int KC, const double* __restrict__ Mrow, double* cl_buf, unsigned* cl_cnt,
-                                                              unsigned* cl_err, int Nc) {
-    constexpr int N = 2 * NH;
+                                                              unsigned* cl_err, int Nc, int n_rt, AnyPlan pl) {
+    const int N = NH ? 2 * NH : n_rt;             // NH = 0: run-time length (any N)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    typename ShbRef<NH>::type s = ShbRef<NH>::get(smem, N, pl);
     const int tid = threadIdx.x;
     const size_t prob = blockIdx.x / KC;
     stack += prob * (size_t)(n_iters + 1) * Nc;
@@ -441,7 +517,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
         }
         __syncthreads();
         if (KC > 1) { if (!cluster_gemv(cl, s.r, s.c, Nc, tid)) return; }
-        else gemv_cols(ST, s.r, s.c, s.part, Nc, tid);
+        else shb_gemv<NH>(ST, s.r, s.c, s.part, Nc, tid);
     }
     to_grid(s.c, s.g);
     if (cl.k == 0)
@@ -452,10 +528,10 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
 template <int NH>
 __global__ __launch_bounds__(NT) void shb_transform_kernel(const double* __restrict__ in, double* __restrict__ out, int which,
                                                            const cplx* __restrict__ tw_g, const cplx* __restrict__ twN_g,
-                                                           const cplx* __restrict__ tw4_g, const double* __restrict__ W_g) {
-    constexpr int N = 2 * NH;
+                                                           const cplx* __restrict__ tw4_g, const double* __restrict__ W_g, int n_rt, AnyPlan pl) {
+    const int N = NH ? 2 * NH : n_rt;             // NH = 0: run-time length (any N)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ShbShared<NH>& s = *reinterpret_cast<ShbShared<NH>*>(smem);
+    typename ShbRef<NH>::type s = ShbRef<NH>::get(smem, N, pl);
     const int tid = threadIdx.x;
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     for (int i = tid; i < N; i += NT) {
@@ -542,10 +618,12 @@ public:
         Nc = cfg.npts;
         N = cnts ? 2 * Nc : Nc;                    // "Continuous": npts modes, dealias 2 => vectors live on the 2*npts Gauss grid
         NH = N / 2;
-        if (dispatch([](auto) { return SMO_OK; }) != SMO_OK) {      // compile-time instantiations: 2^k and 3 * 2^k
-            set_error("SHB23: the grid length must be 2^k or 3*2^k in [64, 1024], got %d", N);
-            return SMO_ERR_UNSUPPORTED;
-        }
+        // compile-time instantiations: grid lengths 2^k and 3 * 2^k in [64, 1024]; every other length from 4 to 1024 (odd ones included;
+        // the reference takes any N) runs the same kernels with the length a run-time value (NH = 0: any_len; SMO_SHB_ANY=1 forces it)
+        if (N < 4 || N > NT) { set_error("SHB23: the grid length must be in [4, %d], got %d", NT, N); return SMO_ERR_UNSUPPORTED; }
+        any_len = (N & 1) || !has_instance(NH);
+        { const char* e = getenv("SMO_SHB_ANY"); if (e && atoi(e) == 1) any_len = true; }
+        if (any_len) plan = any_plan(N);
         Lz = cfg.x1 - cfg.x0;
         n_comp = 1;
         vec_len = (size_t)N;
@@ -576,19 +654,20 @@ public:
             }
         }
         std::vector<cplx> twN = twiddles(N), t4 = twiddles(4 * N);
+        const std::vector<cplx> twF = any_len ? twN : twiddles(NH);      // table of the complex transform: full length (any N) | half length
         twN.resize(NH);
-        t4.resize(NH + 1);
+        t4.resize(any_len ? N : NH + 1);
         SMO_TRY(pool.upload(&d_S, S, stream));
         SMO_TRY(pool.upload(&d_ST, ST, stream));
         SMO_TRY(pool.upload(&d_W, W, stream));
-        SMO_TRY(pool.upload(&d_tw, twiddles(NH), stream));
+        SMO_TRY(pool.upload(&d_tw, twF, stream));
         SMO_TRY(pool.upload(&d_twN, twN, stream));
         SMO_TRY(pool.upload(&d_tw4, t4, stream));
         SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * snapshot_doubles));
         SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
         // latency mode: a single problem is spread over KC = N^2/8192 CUs (64 KB of operator rows per CU); SMO_SHB_CLUSTER=0 disables
         const char* env = getenv("SMO_SHB_CLUSTER");
-        if (cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) {    // N = 1024 would not fit the LDS
+        if (!any_len && cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) {    // N = 1024 would not fit the LDS
             KC = (Nc * Nc + 8191) / 8192;                      // members: at most 64 KB of operator rows each ...
             while (Nc % KC != 0) ++KC;                         // ... and the same number of rows (Nc = 384: 24 members of 16 rows)
         }
@@ -604,7 +683,15 @@ public:
         return SMO_OK;
     }
 
+    bool any_len = false;        // no instantiation for this length: the kernels' NH = 0 form
+    AnyPlan plan{};
+    static bool has_instance(int nh) {
+        for (int v : {32, 48, 96, 192, 384, 64, 128, 256, 512}) if (v == nh) return true;
+        return false;
+    }
+    template <int H> size_t work_lds() const { if constexpr (H == 0) return shb_any_lds(N); else return sizeof(ShbShared<H>); }
     template <class F> int dispatch(F f) {
+        if (any_len) return f(std::integral_constant<int, 0>());
         switch (NH) {
             case 32: return f(std::integral_constant<int, 32>());
             case 48: return f(std::integral_constant<int, 48>());       // N = 96, 192, 384, 768: one radix-3 stage
@@ -626,15 +713,15 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 auto kern = shb_forward_kernel<H>;
-                const size_t lds_cl = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
+                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
                 SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                 const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
-                const size_t lds = kc > 1 ? lds_cl : sizeof(ShbShared<H>);
+                const size_t lds = kc > 1 ? lds_cl : work_lds<H>();
                 *used = kc;
                 SMO_TRY(reset_cluster_words());
                 ScopedTimer t(timing, k_fwd, stream);
                 hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, X[0], d_stack, d_out, d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                                   1.0 / Lz, cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc, cnts ? 1 : 0);
+                                   1.0 / Lz, cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc, cnts ? 1 : 0, N, plan);
                 return SMO_OK;
             });
         }));
@@ -654,24 +741,24 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 const int No = cnts ? Nc : N;            // operator dimension
-                const size_t lds_cl = sizeof(ShbShared<H>) + (KC > 1 ? (size_t)(No / KC) * No * sizeof(double) : 0);
+                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)(No / KC) * No * sizeof(double) : 0);
                 auto go = [&](auto kern, auto&& fire) -> int {
                     SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                     const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
                     *used = kc;
                     SMO_TRY(reset_cluster_words());
                     ScopedTimer t(timing, k_adj, stream);
-                    fire(kern, kc, kc > 1 ? lds_cl : sizeof(ShbShared<H>));
+                    fire(kern, kc, kc > 1 ? lds_cl : work_lds<H>());
                     return SMO_OK;
                 };
                 if (cnts)
                     return go(shb_adjoint_cnts_kernel<H>, [&](auto kern, int kc, size_t lds) {
                         hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, d_stack, grad[0], d_ST, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                                           cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc);
+                                           cfg.n_iters, kc, d_S, d_clbuf, d_clcnt, d_clerr, Nc, N, plan);
                     });
                 return go(shb_adjoint_kernel<H>, [&](auto kern, int kc, size_t lds) {
                     hipLaunchKernelGGL(kern, dim3(cfg.batch * kc), dim3(NT), lds, stream, d_stack, grad[0], d_S, d_W, d_tw, d_twN, d_tw4, cfg.dt,
-                                       cfg.n_iters, kc, d_ST, d_clbuf, d_clcnt, d_clerr);
+                                       cfg.n_iters, kc, d_ST, d_clbuf, d_clcnt, d_clerr, N, plan);
                 });
             });
         });
@@ -693,9 +780,9 @@ public:
         int rc = dispatch([&](auto nh) {
             constexpr int H = decltype(nh)::value;
             auto kern = shb_transform_kernel<H>;
-            const size_t lds = sizeof(ShbShared<H>);
+            const size_t lds = work_lds<H>();
             SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, stream, d_in, d_o, which, d_tw, d_twN, d_tw4, d_W);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, stream, d_in, d_o, which, d_tw, d_twN, d_tw4, d_W, N, plan);
             return SMO_OK;
         });
         if (rc == SMO_OK && hipMemcpyAsync(out, d_o, N * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) rc = SMO_ERR_HIP;

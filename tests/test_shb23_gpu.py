@@ -48,6 +48,56 @@ def test_forward_adjoint_vs_oracle(N, n):
     assert abs(shb23.Inner_Prod(X, g[0], dom) - o.inner(X, go[0])) <= RTOL * abs(o.inner(X, go[0]))
 
 
+# ---- any N: the kernels' run-time-length form (csrc/shb23.hip, NH = 0) ------------------------------------------------------------
+def test_any_length_transforms_match_reference_helpers(monkeypatch):
+    """The full-length (Makhoul N-point) DCT pair of the any-N path against the vectors the REFERENCE's helpers produced: N = 8 (a length
+    without an instantiation) and N = 512 forced through the any-N kernels."""
+    g = np.load(os.path.join(GOLDEN, "shb_helpers.npz"))
+    monkeypatch.setenv("SMO_SHB_ANY", "1")
+    for N in (8, 512):
+        dom = shb23.SHBDomain(N)
+        v = g["v%d" % N]
+        assert rel(shb23.transform(v, dom), g["T%d" % N]) < 1e-13
+        assert rel(shb23.transformInverse(v, dom), g["Tinv%d" % N]) < 1e-13
+        assert rel(shb23.transformAdjoint(v, dom), g["Tadj%d" % N]) < 1e-13
+        assert rel(shb23.transformInverseAdjoint(v, dom), g["Tinvadj%d" % N]) < 1e-13
+        assert np.array_equal(shb23.weightMatrixDisc(dom), g["W%d" % N])
+        assert abs(shb23.Inner_Prod_Discrete(v, g["T%d" % N], dom) - g["ip%d" % N]) < 1e-13 * abs(g["ip%d" % N])
+
+
+@pytest.mark.parametrize("N,n", [(20, 30), (33, 30), (50, 40), (100, 60), (127, 30), (250, 40), (500, 20), (1000, 8), (1023, 6)])
+def test_any_n_vs_oracle(N, n):
+    """Grid lengths without an instantiation: other prime factors, odd N, a prime N."""
+    test_forward_adjoint_vs_oracle(N, n)
+
+
+@pytest.mark.parametrize("N,n", [(20, 30), (50, 40), (100, 60), (250, 20), (333, 10)])
+def test_any_n_continuous_vs_oracle(N, n):
+    test_continuous_forward_adjoint_vs_oracle(N, n)
+
+
+@pytest.mark.parametrize("N,cont", [(64, False), (512, False), (128, True)])
+def test_any_length_kernels_match_the_instantiated_ones(N, cont, monkeypatch):
+    """SMO_SHB_ANY=1 sends an instantiated length through the any-N form (one workgroup, full-length transforms): same J, gradient and last
+    snapshot to rounding (N = 512 / 256 modes: against the cluster mode)."""
+    from oracle import shb23 as osh
+    n = 40
+    o = (osh.SHB23CntsOracle if cont else osh.SHB23Oracle)(N, dt=1e-2, N_ITERS=n)
+    X = (osh.synthetic_ic_cnts if cont else osh.synthetic_ic)(o, 42, 0.0019)
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("SMO_SHB_ANY", force)
+        dom = shb23.SHBDomain(N, dealias=2) if cont else shb23.SHBDomain(N)
+        buf = shb23.GEN_BUFFER(N, dom, n)
+        if cont:
+            J = shb23.FWD_Solve_IVP_Cnts([X], dom, buf, n, 1e-2); g = shb23.ADJ_Solve_IVP_Cnts([X], dom, buf, n, 1e-2)[0]
+        else:
+            J = shb23.FWD_Solve_IVP_Discrete([X], dom, buf, n, 1e-2); g = shb23.ADJ_Solve_IVP_Discrete([X], dom, buf, n, 1e-2)[0]
+        res.append((J, g, np.array(buf['A_fwd'][:, -1])))
+    (J0, g0, s0), (J1, g1, s1) = res
+    assert abs(J1 - J0) <= 1e-11 * abs(J0) and rel(g1, g0) < 1e-9 and rel(s1, s0) < 1e-10
+
+
 def test_config3_against_committed_oracle_output():
     """BASELINE config 3: N=512 (Npts=256 x dealias 2), dt=0.01, T=20 (2000 steps)."""
     gold = np.load(os.path.join(GOLDEN, "oracle_shb23_c3.npz"))
@@ -73,9 +123,10 @@ def test_taylor_and_ic_generation():
     assert np.all(np.abs(AA[4, :4] - 2.0) < 5e-3), AA
 
 
-def test_batch_and_errors():
+@pytest.mark.parametrize("N", [64, 50])      # 50: no instantiation, the any-N form
+def test_batch_and_errors(N):
     from oracle import shb23 as osh
-    N, n, B = 64, 20, 3
+    n, B = 20, 3
     o = osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n)
     Xs = np.stack([osh.synthetic_ic(o, s, 0.0019) for s in range(B)])
     ctx = shb23.SHBDomain(N).context(1e-2, n, batch=B)
@@ -86,7 +137,7 @@ def test_batch_and_errors():
     with pytest.raises(_capi.SmoError):
         ctx.adjoint(None, "Continuous")
     with pytest.raises(_capi.SmoError):
-        _capi.Context(_capi.SMO_SHB23, 48, (-20., 20.), 1e-2, 5, -0.1)
+        _capi.Context(_capi.SMO_SHB23, 1025, (-20., 20.), 1e-2, 5, -0.1)      # one workgroup of 1024 threads per problem: N <= 1024
 
 
 # ---- "Continuous" formulation (Npts modes, scale-2 grid vectors; FWD_Solve_SHB23.py:398-523, 685-794) --------------------------
