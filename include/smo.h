@@ -60,12 +60,14 @@ enum { SMO_ADJ_DISCRETE = 0, SMO_ADJ_CONTINUOUS = 1 };          /* `adjoint_type
 
 typedef struct smo_config {
     int    kind;        /* SMO_SH23 | SMO_SHB23 | SMO_KDYN | SMO_POIS */
-    int    npts;        /* Npts as the reference's Generate_IC receives it (SH23 256, SHB23 512, KDYN 128).  SHB23: compile-time instantiations 2^k, 3*2^k in
-                           [64, 1024], anything else SMO_ERR_UNSUPPORTED.  SH23: ANY Npts >= 4 (instantiated: 2^k, 3*2^k, 5*2^k, 7*2^k, 15*2^k in [16, 1024];
-                           every other length, odd ones included, runs the any-length kernels of csrc/sh23.hip).  KDYN: ANY even Npts >= 6, like the reference (FWD_Solve_KDyn.py:362-450, :1029) — tuned
-                           kernels for 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 100, 112, 120, 128, 144, 160, 192, 200, 224, 240,
-                           256, 320; every other size (other prime factors of 3 Npts / 2, odd grids) runs unfused kernels whose transform length is a
-                           run-time value (csrc/kdyn_any.hpp; 2-4x slower per grid point) */
+    int    npts;        /* Npts as the reference's Generate_IC receives it (SH23 256, SHB23 512, KDYN 128).  Like the reference, every kind takes the size it
+                           is handed: SH23 ANY Npts >= 4; SHB23 ANY grid length in [4, 1024] (Continuous: Npts modes on the 2*Npts grid, Npts <= 512);
+                           KDYN ANY even Npts >= 6 (FWD_Solve_SH23.py:279-332, FWD_Solve_SHB23.py:196-217, FWD_Solve_KDyn.py:362-450).  Tuned kernels
+                           (compile-time transform lengths with factors 2, 3, 5, 7) exist for SH23 2^k, 3*2^k, 5*2^k, 7*2^k, 15*2^k in [16, 1024]; SHB23 2^k,
+                           3*2^k in [64, 1024]; KDYN 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 100, 112, 120, 128, 144, 160, 192, 200,
+                           224, 240, 256, 320.  Every other size (other prime factors, odd lengths) runs the same pipeline with the transform length a
+                           run-time value (csrc/kdyn_any.hpp, sh23_*_any, the SHB23 kernels' NH = 0 form): 1.4-4x slower per grid point.  Outside these
+                           ranges: SMO_ERR_UNSUPPORTED */
     double x0, x1;      /* interval of every axis: SH23 (0,12pi), SHB23 (-20,20), KDYN (0,2pi) */
     double dt;          /* time step */
     int    n_iters;     /* N_ITERS (the forward solve executes N_ITERS+1 steps for SH23/KDYN, like the reference) */

@@ -240,6 +240,7 @@ __device__ __forceinline__ void gemv_any(const double* __restrict__ M, const dou
 }
 template <int NH> __device__ __forceinline__ void shb_gemv(const double* __restrict__ M, const double* v, double* out, double* part, int N, int tid) {
     if constexpr (NH != 0) gemv_cols(M, v, out, part, N, tid);
+    else if ((N & 1) == 0) gemv_cols(M, v, out, part, N, tid);      // even N: the 16-byte column-pair stream (its group count adapts to N)
     else gemv_any(M, v, out, part, N, tid);
 }
 
