@@ -93,6 +93,25 @@ __device__ __forceinline__ size_t u_off(int c, int x, size_t i, const Geom& g) {
     return (((size_t)c * nt + i / UT) * g.G + x) * UT + (i % UT);
 }
 
+// Streaming loads of the fused x passes: data a step reads once and nobody reads again soon — the velocity tile (bit 1), the kept forward
+// state B_f (bit 2) and the running sum (bit 4) of the adjoint pass — can be marked non-temporal so that they do not displace the spectra
+// that the neighbouring y passes produce / consume from the caches behind L2 (SMO_X_NT: bit mask, 0 = plain loads).
+#ifndef SMO_X_NT
+#define SMO_X_NT 1
+#endif
+#ifndef SMO_Z_NT
+#define SMO_Z_NT 0
+#endif
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <bool NTL> __device__ __forceinline__ cplx ld_cplx(const cplx* p) {
+    if (NTL) { const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(p)); return mk(v.x, v.y); }
+    return *p;
+}
+template <bool NTL> __device__ __forceinline__ cplx ld_pair(const double* q) {        // two consecutive grid values (16-byte aligned: even flat index)
+    if (NTL) { const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(q)); return mk(v.x, v.y); }
+    return mk(q[0], q[1]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // z pass, inverse (coefficients -> Tz), rows contiguous.  NBT (ix,iy) row triples per workgroup.
 // ---------------------------------------------------------------------------------------------------------
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
             for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
             continue;
         }
-        for (int c = 0; c < 3; ++c) V0[c] = state0[c * cs + e];
+        for (int c = 0; c < 3; ++c) V0[c] = ld_cplx<(SMO_Z_NT & 1) != 0>(state0 + c * cs + e);
         if (MODE == ZF_FWD_UPDATE) {
             cplx F[3];                                  // N^ = i k x E^
             for (int c = 0; c < 3; ++c) {
@@ -249,7 +268,10 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
                 for (int c = 0; c < 3; ++c) { cplx bf = snap[c * cs + e]; E[c] = mk(E[c].re - 2.0 * bf.re, E[c].im - 2.0 * bf.im); }
             cnab_mode(k, k2, alpha, beta, V0, E, V1);
         }
-        for (int c = 0; c < 3; ++c) out0[c * cs + e] = V1[c];
+        for (int c = 0; c < 3; ++c) {
+            if (SMO_Z_NT & 2) __builtin_nontemporal_store(d2_t{V1[c].re, V1[c].im}, reinterpret_cast<d2_t*>(out0 + c * cs + e));
+            else out0[c * cs + e] = V1[c];
+        }
         if (NEXT != NX_NONE) {                          // the new state (or its curl) replaces the spectrum in the tile
             for (int c = 0; c < 3; ++c) {
                 const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
@@ -437,8 +459,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
                         for (int c = 0; c < 3; ++c) {
-                            const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g);
-                            U0[k][c] = mk(q[0], q[1]);
+                            U0[k][c] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
                         }
             }
         }
@@ -452,7 +473,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
             for (int k = 0; k < 3; ++k)
                 for (int c = 0; c < 3; ++c) {
                     if (i == 0) U[k][c] = U0[k][c];
-                    else { const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g); U[k][c] = mk(q[0], q[1]); }
+                    else U[k][c] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
                 }
             auto last_stage = [&](int f, cplx (&out)[3][3]) {
 #pragma unroll
@@ -544,14 +565,14 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
     auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
 
-    auto stage_in = [&](const cplx* src) {                     // spectra of one field group -> Hermitian-extended lines in the tile
+    auto stage_in = [&](const cplx* src, auto ntl) {           // spectra of one field group -> Hermitian-extended lines in the tile
 #pragma unroll
         for (int i = 0; i < SCNT; ++i) {
             const int t = tid + i * NT;
             if (t >= NITEM) break;
             const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
             cplx X1 = mk(0, 0), X2 = mk(0, 0);
-            if (line_ok(p)) { const cplx* q = src + tx_off(c, kx, i0 + 2 * p, g); X1 = q[0]; X2 = q[1]; }
+            if (line_ok(p)) { const cplx* q = src + tx_off(c, kx, i0 + 2 * p, g); X1 = ld_cplx<decltype(ntl)::value>(q); X2 = ld_cplx<decltype(ntl)::value>(q + 1); }
             const int b = c * HP + p;
             if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);
             else {
@@ -595,7 +616,10 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
                     const int t = tid + i * NT, p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
-                    if (t < NITEM && line_ok(p)) { const cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g); old_sum[i][0] = q[0]; old_sum[i][1] = q[1]; }
+                    if (t < NITEM && line_ok(p)) {
+                        const cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g);
+                        old_sum[i][0] = ld_cplx<(SMO_X_NT & 4) != 0>(q); old_sum[i][1] = ld_cplx<(SMO_X_NT & 4) != 0>(q + 1);
+                    }
                 }
             }
         });
@@ -611,14 +635,19 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
             cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g);
             cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
             if (acc) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
-            q[0] = v0;
-            q[1] = v1;
+            if ((SMO_X_NT & 8) && acc) {                           // the running sum comes back one whole step later
+                __builtin_nontemporal_store(d2_t{v0.re, v0.im}, reinterpret_cast<d2_t*>(q));
+                __builtin_nontemporal_store(d2_t{v1.re, v1.im}, reinterpret_cast<d2_t*>(q + 1));
+            } else {
+                q[0] = v0;
+                q[1] = v1;
+            }
         }
     };
 
     // ---- omega: spectrum -> grid, kept in registers -------------------------------------------------------------------------
     cplx Wom[ICNT][3][3], Wy[ICNT][3][3];
-    stage_in(sp.inA);
+    stage_in(sp.inA, std::false_type());
     read_win(Wom);
 #pragma unroll
     for (int i = 0; i < ICNT; ++i) {                            // the velocity is requested before the barrier: in flight while the others read
@@ -626,7 +655,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
         if (t < HP * S3 && line_ok(p))
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                for (int k = 0; k < 3; ++k) { const double* q = gridU + u_off(c, j + S3 * k, i0 + 2 * p, g); Wy[i][c][k] = mk(q[0], q[1]); }
+                for (int k = 0; k < 3; ++k) Wy[i][c][k] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
     }
     __syncthreads();
     // ---- F1 = omega x U -> forward -> out A --------------------------------------------------------------------------------
@@ -642,7 +671,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     forward_and_store(sp.outA, false);
     __syncthreads();
     // ---- B_f: spectrum -> grid; F2' = omega x B_f -> forward -> running sum (out B) -----------------------------------------------
-    stage_in(sp.inB);
+    stage_in(sp.inB, std::integral_constant<bool, (SMO_X_NT & 2) != 0>());
     read_win(Wy);
     __syncthreads();
 #pragma unroll
