@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-KDYN_SOURCES = ("kdyn.hip", "fft_lds.hpp", "comm.hpp", "smo_common.hpp")     # the translation unit the KDyn kernels are compiled from
+KDYN_SOURCES = ("kdyn.hip", "kdyn_any.hpp", "fft_lds.hpp", "comm.hpp", "smo_common.hpp")     # the translation unit the KDyn kernels are compiled from
 
 
 def source_sha():

@@ -93,11 +93,13 @@ __device__ __forceinline__ size_t u_off(int c, int x, size_t i, const Geom& g) {
     return (((size_t)c * nt + i / UT) * g.G + x) * UT + (i % UT);
 }
 
-// Streaming loads of the fused x passes: data a step reads once and nobody reads again soon — the velocity tile (bit 1), the kept forward
-// state B_f (bit 2) and the running sum (bit 4) of the adjoint pass — can be marked non-temporal so that they do not displace the spectra
-// that the neighbouring y passes produce / consume from the caches behind L2 (SMO_X_NT: bit mask, 0 = plain loads).
+// Streaming loads of the fused x passes.  At 128^3 a step hands ~1 GB from kernel to kernel (Ty, the EMF's spectrum, Tz) and those hand-overs can be
+// served by the 256-MB cache behind the L2s — unless once-read streams displace them.  SMO_X_NT marks such streams non-temporal (bit mask):
+//   1  the velocity tile (both passes): 170 MB per launch, the same every step            forward x pass 90.8 -> 80.4 us, adjoint 164.0 -> 159.7 us
+//  16  the forward pass's input spectrum where a tile reads whole 128-byte lines (G <= 192) y<fwd> 35.3 -> 33.9 us; hurts with half-line tiles (G = 384)
+//   2  the kept forward state B_f, 4 / 8 the running sum's loads / stores, 32 omega's spectrum (adjoint pass): measured, no gain (profiles/r02_nt_streams.txt)
 #ifndef SMO_X_NT
-#define SMO_X_NT 1
+#define SMO_X_NT 17
 #endif
 #ifndef SMO_Z_NT
 #define SMO_Z_NT 0
@@ -430,7 +432,9 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
             cplx X1 = mk(0, 0), X2 = mk(0, 0);
             if (line_ok(p)) {
                 const cplx* src = ((f == 0) ? sp.inA : sp.inB) + tx_off(c, kx, i0 + 2 * p, g);
-                X1 = src[0]; X2 = src[1];
+                // (forward pass, tiles of whole 128-byte lines: its input spectrum is dead once read — non-temporal, so that the hit does not renew it)
+                constexpr bool NTIN = (SMO_X_NT & 16) != 0 && MODE == X_FUSED_FWD && T >= 8;
+                X1 = ld_cplx<NTIN>(src); X2 = ld_cplx<NTIN>(src + 1);
             }
             const int b = fc * HP + p;
             if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);                    // c2r ignores the imaginary part of kx = 0
@@ -647,7 +651,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
 
     // ---- omega: spectrum -> grid, kept in registers -------------------------------------------------------------------------
     cplx Wom[ICNT][3][3], Wy[ICNT][3][3];
-    stage_in(sp.inA, std::false_type());
+    stage_in(sp.inA, std::integral_constant<bool, (SMO_X_NT & 32) != 0>());      // omega's spectrum is dead once read
     read_win(Wom);
 #pragma unroll
     for (int i = 0; i < ICNT; ++i) {                            // the velocity is requested before the barrier: in flight while the others read

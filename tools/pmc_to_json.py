@@ -38,7 +38,7 @@ def source_sha():
     import hashlib
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "spheremanopt_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("kdyn.hip", "fft_lds.hpp", "comm.hpp", "smo_common.hpp"):
+    for f in ("kdyn.hip", "kdyn_any.hpp", "fft_lds.hpp", "comm.hpp", "smo_common.hpp"):
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
