@@ -338,41 +338,60 @@ inline AnyPlan any_plan(int L) {
     return p;
 }
 
+// One butterfly of radix R in {2, 3, 4, 5, 7}: reads its R inputs, writes its R outputs (the compile-time butterflies above).
+template <int R, bool INV>
+__device__ __forceinline__ void any_bfly(const cplx* x, cplx* y, int xs, int s, const cplx* tw, int ps, bool twid) {
+    cplx v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = x[k * xs];
+    Butterfly<R, INV>::run(v);
+    y[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) y[s * k] = twid ? twmul<INV>(v[k], tw[ps * k]) : v[k];
+}
+
 // NB transforms of length L, element (b, pos) at b * L + pos, in `src`; ping-pong with `dst`; returns the buffer that holds the result.
 // Stage invariant n * s == L (see the top of this file):  y[q + s (R p + j)] = w_n^{p j} sum_k x[q + s (p + k n/R)] w_R^{j k}.
 // tw[k] = exp(-2 pi i k / L), in the LDS like the buffers (the callers copy it there: one table load per multiply-add from global
-// memory instead made the 3-D passes 1.5x slower).  Radices 2 and 4 need no table for w_R (+-1, +-i).  Ends with a barrier.
+// memory instead made the 3-D passes 1.5x slower).  Stages of radix 2, 3, 4, 5, 7 run one BUTTERFLY per thread (R reads and R writes for R
+// outputs); a stage whose radix is a larger prime runs one OUTPUT per thread as a direct sum over the radix (p multiply-adds per point, no
+// registers proportional to p).  Ends with a barrier.
 template <bool INV>
 __device__ __forceinline__ cplx* any_fft(cplx* src, cplx* dst, const cplx* tw, const AnyPlan& pl, int NB, int tid, int nthr) {
     const int L = pl.L;
     int n = L, s = 1;
     for (int st = 0; st < pl.nst; ++st) {
-        const int R = pl.r[st], M = n / R, wstep = L / R;
-        for (int t = tid; t < NB * L; t += nthr) {
-            const int b = t / L, o = t - b * L;
-            const int q = o % s, rj = o / s, j = rj % R, p = rj / R;
-            const cplx* x = src + (size_t)b * L + q + s * p;
-            const int xs = s * M;
-            cplx acc;
-            if (R == 4) {                               // forward: sum_k x_k (-i)^{j k}; inverse: (+i)^{j k}
-                const cplx x0 = x[0], x1 = x[xs], x2 = x[2 * xs], x3 = x[3 * xs];
-                const cplx e = (j & 1) ? x0 - x2 : x0 + x2, d = (j & 1) ? x1 - x3 : x1 + x3;
-                if (j == 0) acc = e + d;
-                else if (j == 2) acc = e - d;
-                else acc = ((j == 1) != INV) ? e + mul_mi(d) : e + mul_i(d);
-            } else if (R == 2) {
-                acc = j ? x[0] - x[xs] : x[0] + x[xs];
-            } else {
-                acc = x[0];
-                int e = 0;                              // (j k) mod R
+        const int R = pl.r[st], M = n / R, xs = s * M;
+        if (R <= 5 || R == 7) {
+            const int PER = L / R;
+            for (int t = tid; t < NB * PER; t += nthr) {
+                const int b = t / PER, jj = t - b * PER, p = jj / s, q = jj - p * s;
+                const cplx* x = src + (size_t)b * L + q + s * p;
+                cplx* y = dst + (size_t)b * L + q + s * R * p;
+                switch (R) {
+                    case 2: any_bfly<2, INV>(x, y, xs, s, tw, p * s, M > 1); break;
+                    case 3: any_bfly<3, INV>(x, y, xs, s, tw, p * s, M > 1); break;
+                    case 4: any_bfly<4, INV>(x, y, xs, s, tw, p * s, M > 1); break;
+                    case 5: any_bfly<5, INV>(x, y, xs, s, tw, p * s, M > 1); break;
+                    default: any_bfly<7, INV>(x, y, xs, s, tw, p * s, M > 1); break;
+                }
+            }
+        } else {
+            const int wstep = L / R;
+            for (int t = tid; t < NB * L; t += nthr) {
+                const int b = t / L, o = t - b * L;
+                const int q = o % s, rj = o / s, j = rj % R, p = rj / R;
+                const cplx* x = src + (size_t)b * L + q + s * p;
+                cplx acc = x[0];
+                int e = 0;                                  // (j k) mod R
                 for (int k = 1; k < R; ++k) {
                     e += j; if (e >= R) e -= R;
                     const cplx w = tw[e * wstep], v = x[k * xs];
                     acc = acc + (INV ? mul_conj(v, w) : v * w);
                 }
+                if (M > 1 && j) { const cplx w = tw[p * s * j]; acc = INV ? mul_conj(acc, w) : acc * w; }
+                dst[t] = acc;
             }
-            if (M > 1 && j) { const cplx w = tw[p * s * j]; acc = INV ? mul_conj(acc, w) : acc * w; }
-            dst[t] = acc;
         }
         __syncthreads();
         cplx* sw = src; src = dst; dst = sw;

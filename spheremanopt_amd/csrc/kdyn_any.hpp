@@ -153,10 +153,11 @@ __global__ __launch_bounds__(1024) void kda_x_pass(XSpec sp, const double* __res
     cplx* P[3] = {any_lds, any_lds + (size_t)NB * L, any_lds + (size_t)2 * NB * L};      // (the third only in the adjoint pass)
     cplx* tws = any_lds + (size_t)(mode == X_FUSED_ADJ ? 3 : 2) * NB * L;
     any_load_tw(tws, tw, L, tid, NT);
+    // (the lambdas are always inlined: a closure that captures by reference lives in private memory and must not be passed by address)
     // b = c * HP + p; the second line of the last pair is absent when the plane has an odd number of points
-    auto ok1 = [&](int p) { return i0 + 2 * p < plane; };
-    auto ok2 = [&](int p) { return i0 + 2 * p + 1 < plane; };
-    auto load_spec = [&](const cplx* src, cplx* dst) {              // Hermitian-extended, zero-padded lines X1 + i X2
+    auto ok1 = [&](int p) __attribute__((always_inline)) { return i0 + 2 * p < plane; };
+    auto ok2 = [&](int p) __attribute__((always_inline)) { return i0 + 2 * p + 1 < plane; };
+    auto load_spec = [&](const cplx* src, cplx* dst) __attribute__((always_inline)) {              // Hermitian-extended, zero-padded lines X1 + i X2
         for (int t = tid; t < NB * L; t += NT) dst[t] = mk(0, 0);
         __syncthreads();
         for (int t = tid; t < NB * g.a; t += NT) {                  // p fastest
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(1024) void kda_x_pass(XSpec sp, const double* __res
         }
         __syncthreads();
     };
-    auto split_store = [&](const cplx* R, cplx* dst, bool acc) {    // spectra of the two real lines, kx = 0..a-1
+    auto split_store = [&](const cplx* R, cplx* dst, bool acc) __attribute__((always_inline)) {    // spectra of the two real lines, kx = 0..a-1
         for (int t = tid; t < NB * g.a; t += NT) {
             const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
             if (!ok1(p)) continue;
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(1024) void kda_x_pass(XSpec sp, const double* __res
             if (ok2(p)) q[1] = v1;
         }
     };
-    auto grid_pair = [&](int c, int x, int p) -> cplx {            // the internal U field, flat grid layout
+    auto grid_pair = [&](int c, int x, int p) __attribute__((always_inline)) -> cplx {            // the internal U field, flat grid layout
         const double* q = gridU + grid_off(c, x, i0 + 2 * p, g);
         return mk(q[0], ok2(p) ? q[1] : 0.0);
     };
     // X x Y at every point of the tile, both lines of a pair at once (.re / .im); in place on Y's buffer unless dst is given
-    auto cross = [&](const cplx* X, const cplx* Y, cplx* dst, bool x_is_U, bool y_is_U) {
+    auto cross = [&](const cplx* X, const cplx* Y, cplx* dst, bool x_is_U, bool y_is_U) __attribute__((always_inline)) {
         for (int t = tid; t < HP * L; t += NT) {
             const int p = t % HP, x = t / HP;
             if (!ok1(p)) { for (int c = 0; c < 3; ++c) dst[(size_t)(c * HP + p) * L + x] = mk(0, 0); continue; }

@@ -202,8 +202,11 @@ template <> struct DctWork<0> {
     int N;
     AnyPlan pl;
 };
+// (forced inline, like load_tables<0> below: the work area of the any-N form is a kernel-local struct of LDS pointers, and a call that is NOT
+// inlined would hand the callee a flat pointer into the caller's private memory — when the inliner stopped inlining dct3<0> into the
+// Continuous adjoint kernel, that kernel returned garbage and a hand-made out-of-line variant faulted with an aperture violation)
 // y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N)) = 2 Re(e^{-i pi k/(2N)} V_k),  V = F_N v,  v[j] = x[2j], v[N-1-j] = x[2j+1]
-template <> __device__ void dct2<0>(DctWork<0>& w, const double* x, double* y, int tid) {
+template <> __device__ __forceinline__ void dct2<0>(DctWork<0>& w, const double* x, double* y, int tid) {
     const int N = w.N;
     for (int n = tid; n < N; n += NT) { const int j = (n & 1) ? N - 1 - (n >> 1) : (n >> 1); w.P[j] = mk(x[n], 0.0); }
     __syncthreads();
@@ -212,7 +215,7 @@ template <> __device__ void dct2<0>(DctWork<0>& w, const double* x, double* y, i
     __syncthreads();
 }
 // y[n] = x[0] + 2 sum_{k>=1} x[k] cos(pi k (2n+1) / (2N)):  v = Re F_N^-1[c_k x_k e^{+i pi k/(2N)}] (c_0 = 1, else 2), y[2j] = v[j], y[2j+1] = v[N-1-j]
-template <> __device__ void dct3<0>(DctWork<0>& w, const double* x, double* y, int tid) {
+template <> __device__ __forceinline__ void dct3<0>(DctWork<0>& w, const double* x, double* y, int tid) {
     const int N = w.N;
     for (int k = tid; k < N; k += NT) { const double a = (k == 0) ? x[0] : 2.0 * x[k]; const cplx t = w.tw4[k]; w.P[k] = mk(a * t.re, -a * t.im); }
     __syncthreads();
@@ -346,7 +349,7 @@ template <> struct ShbRef<0> {
         return ShbShared<0>{DctWork<0>{z, z + N, z + 2 * N, z + 3 * N, N, pl}, d, d + Ne, d + 2 * Ne, d + 3 * Ne, d + 4 * Ne, d + 5 * Ne, d + 5 * Ne + 2 * NT, 0};
     }
 };
-template <> __device__ void load_tables<0>(ShbShared<0>& s, const cplx* tw_g, const cplx*, const cplx* tw4_g, const double* W_g, int tid) {
+template <> __device__ __forceinline__ void load_tables<0>(ShbShared<0>& s, const cplx* tw_g, const cplx*, const cplx* tw4_g, const double* W_g, int tid) {
     for (int i = tid; i < s.w.N; i += NT) { s.w.tw[i] = tw_g[i]; s.w.tw4[i] = tw4_g[i]; s.W[i] = W_g[i]; }
     __syncthreads();
 }
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
     }
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
-    auto tinv_adj = [&](const double* in, double* out) {           // T^-T x = 1/2 s o DCT2(x), s_0 = 1
+    auto tinv_adj = [&](const double* in, double* out) __attribute__((always_inline)) {      // T^-T x = 1/2 s o DCT2(x), s_0 = 1
         dct2(s.w, in, out, tid);
         for (int k = tid; k < N; k += NT) out[k] *= (k & 1) ? -0.5 : 0.5;
         __syncthreads();
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
     }
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
-    auto to_grid = [&](const double* coeff, double* out) {          // T^-1 of a coefficient vector that is zero beyond Nc
+    auto to_grid = [&](const double* coeff, double* out) __attribute__((always_inline)) {      // T^-1 of a coefficient vector that is zero beyond Nc (always inlined: the closure must not be passed by address, see dct2<0>)
         for (int k = tid; k < N; k += NT) s.t[k] = (k == 0) ? coeff[0] : ((k & 1) ? -0.5 : 0.5) * coeff[k];
         __syncthreads();
         dct3(s.w, s.t, out, tid);

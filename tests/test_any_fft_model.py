@@ -1,5 +1,5 @@
 """The run-time-length Stockham chain of csrc/fft_lds.hpp (any_plan / any_fft), replayed in NumPy: same factorisation, same stage formula,
-same one-output-at-a-time evaluation with the radix-2 / radix-4 shortcuts, same index arithmetic into ONE twiddle table — checked against
+same split into butterfly stages (radices 2, 3, 4, 5, 7) and one-output-at-a-time stages (larger primes), same index arithmetic into ONE twiddle table — checked against
 numpy.fft for the lengths the any-size kernels meet (prime factors 2..157, odd and prime lengths).  Runs without a GPU; the device code is
 checked against the oracle in tests/test_kdyn_gpu.py, test_sh23_gpu.py, test_shb23_gpu.py."""
 import numpy as np
@@ -22,7 +22,8 @@ def any_plan(L):
 
 
 def any_fft(x, inverse):
-    """Stage invariant n * s == L:  y[q + s (R p + j)] = w_n^{p j} sum_k x[q + s (p + k n/R)] w_R^{j k}, every w taken from tw[k] = exp(-2 pi i k / L)."""
+    """Stage invariant n * s == L:  y[q + s (R p + j)] = w_n^{p j} sum_k x[q + s (p + k n/R)] w_R^{j k}, every w taken from tw[k] = exp(-2 pi i k / L).
+    Radices 2, 3, 4, 5, 7: one butterfly at a time (R inputs -> R outputs); larger primes: one output at a time as a direct sum."""
     L = len(x)
     tw = np.exp(-2j * np.pi * np.arange(L) / L)
     w = (lambda i: np.conj(tw[i])) if inverse else (lambda i: tw[i])
@@ -31,32 +32,31 @@ def any_fft(x, inverse):
     for R in any_plan(L):
         M, wstep, xs = n // R, L // R, s * (n // R)
         dst = np.empty(L, dtype=complex)
-        for o in range(L):
-            q, rj = o % s, o // s
-            j, p = rj % R, rj // R
-            base = q + s * p
-            if R == 4:
-                x0, x1, x2, x3 = src[base], src[base + xs], src[base + 2 * xs], src[base + 3 * xs]
-                e, d = (x0 - x2, x1 - x3) if (j & 1) else (x0 + x2, x1 + x3)
-                if j == 0:
-                    acc = e + d
-                elif j == 2:
-                    acc = e - d
-                else:
-                    acc = e - 1j * d if ((j == 1) != inverse) else e + 1j * d
-            elif R == 2:
-                acc = src[base] - src[base + xs] if j else src[base] + src[base + xs]
-            else:
+        if R <= 5 or R == 7:
+            for jj in range(L // R):
+                p, q = jj // s, jj % s
+                v = np.array([src[q + s * p + k * xs] for k in range(R)])
+                out = np.array([sum(v[k] * w(((j * k) % R) * wstep) for k in range(R)) for j in range(R)])      # Butterfly<R>
+                for k in range(R):
+                    if k and M > 1:
+                        assert p * s * k < L
+                        out[k] = out[k] * w(p * s * k)
+                    dst[q + s * R * p + s * k] = out[k]
+        else:
+            for o in range(L):
+                q, rj = o % s, o // s
+                j, p = rj % R, rj // R
+                base = q + s * p
                 acc, e = src[base], 0
                 for k in range(1, R):
                     e += j
                     if e >= R:
                         e -= R
                     acc = acc + src[base + k * xs] * w(e * wstep)
-            if M > 1 and j:
-                assert p * s * j < L
-                acc = acc * w(p * s * j)
-            dst[o] = acc
+                if M > 1 and j:
+                    assert p * s * j < L
+                    acc = acc * w(p * s * j)
+                dst[o] = acc
         src, n, s = dst, M, s * R
     assert n == 1 and s == L
     return src
