@@ -66,7 +66,7 @@ typedef struct smo_config {
                            (compile-time transform lengths with factors 2, 3, 5, 7) exist for SH23 2^k, 3*2^k, 5*2^k, 7*2^k, 15*2^k in [16, 1024]; SHB23 2^k,
                            3*2^k in [64, 1024]; KDYN 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 100, 112, 120, 128, 144, 160, 192, 200,
                            224, 240, 256, 320.  Every other size (other prime factors, odd lengths) runs the same pipeline with the transform length a
-                           run-time value (csrc/kdyn_any.hpp, sh23_*_any, the SHB23 kernels' NH = 0 form): 1.4-4x slower per grid point.  Outside these
+                           run-time value (csrc/kdyn_any.hpp, sh23_*_any, the SHB23 kernels' NH = 0 form): 1.4-2.6x slower per grid point.  Outside these
                            ranges: SMO_ERR_UNSUPPORTED */
     double x0, x1;      /* interval of every axis: SH23 (0,12pi), SHB23 (-20,20), KDYN (0,2pi) */
     double dt;          /* time step */
