@@ -317,9 +317,10 @@ __device__ __forceinline__ void fft_inplace_head(cplx* buf, IX ix, TW tw, int ti
 
 // ---------------------------------------------------------------------------------------------------------
 // Run-time-length variant: the transform length is a kernel argument, the radices are the prime factors of L found on the host
-// (any_plan), and every stage is evaluated one OUTPUT per thread as a direct sum over its radix — any length works (a prime factor p
-// costs p multiply-adds per point), at a multiple of the cost of the compile-time chains above.  Used where a size has no tuned
-// instantiation: csrc/kdyn_any.hpp (any even Npts of the 3-D case), the SH23 any-length kernels.
+// (any_plan); stages of radix 2, 3, 4, 5, 7 run the butterflies above, one per thread, a stage whose radix is a larger prime is evaluated
+// one output per thread as a direct sum — any length works (a prime factor p costs p multiply-adds per point), at a multiple of the cost
+// of the compile-time chains above.  Used where a size has no tuned instantiation: csrc/kdyn_any.hpp (any even Npts of the 3-D case), the
+// SH23 any-length kernels, the SHB23 kernels' NH = 0 form.
 // ---------------------------------------------------------------------------------------------------------
 struct AnyPlan {
     int L;            // transform length

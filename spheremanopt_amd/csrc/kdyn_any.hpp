@@ -4,9 +4,9 @@
 // Why: the tuned kernels are compile-time instantiations for G with factors 2, 3, 5, 7; the reference, through Dedalus / FFTW
 // (FWD_Solve_KDyn.py:362-450 builds a Fourier basis for whatever Npts it is handed, :1029 the script's Npts), takes any even Npts.
 // These kernels are the path of every other size: unfused where fusion needed compile-time radices (no register-resident middle
-// section, no fused next z pass), a Stockham chain whose radices are the prime factors of G found at context creation, each stage
-// evaluated one OUTPUT per thread as a direct sum over its radix (so a prime factor p costs p multiply-adds per point: 11, 13, 17 ...
-// are cheap, a large prime G/3 is the O(G p) worst case).  Odd G (Npts = 2 mod 4) is covered too: the last (y,z) line of a plane then has
+// section, no fused next z pass), a Stockham chain whose radices are the prime factors of G found at context creation (fft_lds.hpp,
+// any_fft: butterfly stages for the radices 2, 3, 4, 5, 7, a direct sum per output for a larger prime p — p multiply-adds per point: 11,
+// 13, 17 ... are cheap, a large prime G/3 is the O(G p) worst case).  Odd G (Npts = 2 mod 4) is covered too: the last (y,z) line of a plane then has
 // no partner in the two-real-lines-per-complex-transform packing and is paired with zeros.
 // Slower than the tuned path by design (short runs, LDS ping-pong, no fusion); results agree with the oracle like the tuned kernels' do.
 #pragma once
