@@ -183,6 +183,14 @@ int smo_comm_init(smo_ctx* ctx, const void* id128);
 int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn all_to_all, smo_allreduce_fn all_reduce_sum, void* user);
 /* key 0: pipelined z chunks per exchange; 1: field-group exchanges per forward+adjoint step pair; 2: 1 if the transport is RCCL */
 int smo_comm_get(const smo_ctx* ctx, int key, double* value);
+/* File of the librccl this library bound for smo_comm_unique_id / smo_comm_init (dladdr of its ncclGetUniqueId), "" if none can be
+ * loaded.  A copy already in the process (PyTorch bundles one) is reused, else the system library is loaded; the environment variable
+ * SMO_RCCL_LIB (a path or soname) replaces that search.  What the reference gets from `mpiexec` picking ONE MPI library for every rank
+ * (README.md:83): a process holding two RCCL copies would otherwise not know which one carries the transposes. */
+const char* smo_comm_library(void);
+/* If smo_comm_init / smo_comm_set_transport fail after the transport exists (the ranks chose different checkpoint intervals from their
+ * free HBM, ...), the transport is dropped again: the context is back in its "no communicator" state (smo_forward: SMO_ERR_STATE)
+ * and the call may be repeated. */
 
 /* The exchange buffers hold [chunk][peer][field group][3][a/world][m][G/world/chunks] complex128; peer blocks are contiguous.
  *   z-side buffer: my kx, peer = z block; written by the inverse z pass, read by the forward z pass
@@ -227,6 +235,9 @@ int smo_set_stream(smo_ctx* ctx, void* hip_stream);
  * (0 <= k < smo_timing_classes), its name, number of launches, total milliseconds and the ALGORITHMIC bytes
  * one launch moves (DESIGN.md section "kernels"), so  achieved GB/s = bytes * launches / ms / 1e6. */
 int         smo_timing_enable(smo_ctx* ctx, int on);
+/* time exactly the classes whose bit is set in `class_mask` (bit k = class k; 0 = off); resets the accumulators.  The multi-GPU benchmark
+ * times its dominant kernel class AND the "slab_exchange(all-to-all)" class (events around every grouped send/recv, on the stream it runs on). */
+int         smo_timing_select(smo_ctx* ctx, unsigned long long class_mask);
 int         smo_timing_classes(const smo_ctx* ctx);
 int         smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms,
                            double* bytes_per_launch);

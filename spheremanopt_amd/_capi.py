@@ -24,7 +24,7 @@ EXPORTS = [
     "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get", "smo_timing_hbm_bytes",
     "smo_vec_alloc", "smo_vec_free", "smo_vec_pool_release", "smo_vec_pool_bytes", "smo_vec_upload", "smo_vec_download", "smo_vec_axpby",
     "smo_host_alloc", "smo_host_free",
-    "smo_comm_unique_id", "smo_comm_init", "smo_comm_set_transport", "smo_comm_get",
+    "smo_comm_unique_id", "smo_comm_init", "smo_comm_set_transport", "smo_comm_get", "smo_comm_library", "smo_timing_select",
 ]
 
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)      # smo_alltoall_fn
@@ -113,6 +113,8 @@ def lib():
     L.smo_comm_init.argtypes = [vp, vp]
     L.smo_comm_set_transport.argtypes = [vp, ALLTOALL_FN, ALLREDUCE_FN, vp]
     L.smo_comm_get.argtypes = [vp, C.c_int, dp]
+    L.smo_comm_library.restype = C.c_char_p
+    L.smo_timing_select.argtypes = [vp, C.c_ulonglong]
     _lib = L
     return L
 
@@ -267,17 +269,47 @@ class Context:
         return float(out[0]) if self.batch == 1 else out
 
     # -- device-resident entry points (torch tensors on the context's device, or raw addresses) ------------------------
+    def _check_dev(self, vecs, who):
+        """A device vector of the wrong length or on another GPU would be an out-of-bounds device access, not an exception: refuse it
+        here.  (Raw integer addresses cannot be checked — the caller vouches for them, as across the C-ABI itself.)"""
+        if len(vecs) != self.ncomp and who != "inner":
+            raise ValueError("%s: %d vectors given, the context has %d components" % (who, len(vecs), self.ncomp))
+        want = self.vec_len * self.batch
+        for v in vecs:
+            if isinstance(v, int):
+                continue
+            n = getattr(v, "n", None)
+            if n is None and hasattr(v, "numel"):
+                n = v.numel()
+                if getattr(v, "dtype", None) is not None and getattr(v.dtype, "itemsize", 8) != 8:
+                    raise ValueError("%s: float64 vectors expected, got %s" % (who, v.dtype))
+                if hasattr(v, "is_contiguous") and not v.is_contiguous():
+                    raise ValueError("%s: contiguous vectors expected" % who)
+            if n is not None and int(n) != want:
+                raise ValueError("%s: device vector has %d entries, context expects %d" % (who, int(n), want))
+            dev = getattr(v, "device", None)
+            idx = dev if isinstance(dev, int) else getattr(dev, "index", None)
+            if getattr(dev, "type", "cuda") != "cuda":
+                raise ValueError("%s: vector lives on %s, not on a GPU" % (who, dev))
+            if idx is not None and int(idx) != int(self.cfg.device):
+                raise ValueError("%s: vector lives on device %d, the context on device %d" % (who, int(idx), int(self.cfg.device)))
+
     def forward_dev(self, X):
+        self._check_dev(X, "forward_dev")
         J = np.zeros(self.batch)
         _check(lib().smo_forward_dev(self._h, _ptr_array([_dev_ptr(x) for x in X]), J.ctypes.data_as(C.POINTER(C.c_double))))
         return float(J[0]) if self.batch == 1 else J
 
     def adjoint_dev(self, X, grads, adjoint_type="Discrete"):
+        if X is not None:
+            self._check_dev(X, "adjoint_dev")
+        self._check_dev(grads, "adjoint_dev(grads)")
         _check(lib().smo_adjoint_dev(self._h, _ptr_array([_dev_ptr(x) for x in X]), ADJOINT[adjoint_type],
                                      _ptr_array([_dev_ptr(g) for g in grads])))
         return grads
 
     def inner_dev(self, x, y):
+        self._check_dev([x, y], "inner")
         out = np.zeros(self.batch)
         _check(lib().smo_inner_dev(self._h, _dev_ptr(x), _dev_ptr(y), out.ctypes.data_as(C.POINTER(C.c_double))))
         return float(out[0]) if self.batch == 1 else out
@@ -361,8 +393,14 @@ class Context:
         _check(lib().smo_get(self._h, int(key), C.byref(v)))
         return v.value
 
-    def timing_enable(self, on=True, only=None):
-        """on=False: off; on=True: every kernel class; only=k: just class k (index into timing())."""
+    def timing_enable(self, on=True, only=None, select=None):
+        """on=False: off; on=True: every kernel class; only=k: just class k (index into timing()); select=[k, ...]: exactly those classes."""
+        if select is not None:
+            mask = 0
+            for k in select:
+                mask |= 1 << int(k)
+            _check(lib().smo_timing_select(self._h, mask))
+            return
         _check(lib().smo_timing_enable(self._h, (2 + int(only)) if only is not None else (1 if on else 0)))
 
     def timing(self):

@@ -185,6 +185,7 @@ int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn a2a, smo_allreduce_fn a
     SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
     return ctx->impl->comm_set_transport(a2a, ared, user);
 }
+const char* smo_comm_library(void) { return smo::SlabComm::library_path(); }
 int smo_comm_get(const smo_ctx* ctx, int key, double* value) {
     CHECK_CTX(ctx);
     if (!value || key < 0 || key > 2) { smo::set_error("smo_comm_get: bad argument"); return SMO_ERR_ARG; }
@@ -202,7 +203,14 @@ int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
     ctx->impl->timing.reset();
     ctx->impl->timing.on = (on != 0);
-    ctx->impl->timing.only = (on >= 2) ? on - 2 : -1;
+    ctx->impl->timing.mask = (on >= 2) ? (1ull << (on - 2)) : ~0ull;
+    return SMO_OK;
+}
+int smo_timing_select(smo_ctx* ctx, unsigned long long class_mask) {
+    CHECK_CTX(ctx);
+    ctx->impl->timing.reset();
+    ctx->impl->timing.on = (class_mask != 0);
+    ctx->impl->timing.mask = class_mask;
     return SMO_OK;
 }
 int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->timing.cls.size() : 0; }

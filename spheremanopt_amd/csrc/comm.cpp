@@ -4,7 +4,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <mutex>
+#include <vector>
 
 namespace smo {
 namespace {
@@ -25,13 +27,24 @@ Rccl g_rccl;
 std::once_flag g_once;
 std::string g_load_error;
 
+std::string g_lib_path;       // file the bound ncclGetUniqueId lives in (dladdr): which of the process' RCCL copies this library talks to
+
 void load_rccl() {
-    // a copy already in the process (PyTorch's) wins: RTLD_NOLOAD first, then the system library
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    // a copy already in the process (PyTorch's) wins: RTLD_NOLOAD first, then the system library.  SMO_RCCL_LIB (a path or soname)
+    // replaces the candidate list: the way to pin one copy when a process holds several, and how the tests take librccl away.
+    std::vector<std::string> names = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    if (const char* e = getenv("SMO_RCCL_LIB")) names.assign(1, std::string(e));
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) break; }
-    if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
-    if (!h) { g_load_error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"); return; }
+    std::string why;
+    for (const std::string& n : names) { h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) break; }
+    (void)dlerror();                                       // RTLD_NOLOAD misses are not errors worth reporting: clear the state
+    if (!h) for (const std::string& n : names) {
+        h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+        const char* e = dlerror();                         // ONE call: dlerror() clears the message it returns
+        why += (why.empty() ? "" : "; ") + (e ? std::string(e) : n + ": not found");
+    }
+    if (!h) { g_load_error = "cannot load librccl: " + (why.empty() ? std::string("not found") : why); return; }
     g_rccl.handle = h;
     bool ok = true;
 #define SMO_SYM(field, name)                                                         \
@@ -47,7 +60,9 @@ void load_rccl() {
     SMO_SYM(AllReduce, "ncclAllReduce")
     SMO_SYM(GetErrorString, "ncclGetErrorString")
 #undef SMO_SYM
-    if (!ok) g_rccl.handle = nullptr;
+    if (!ok) { g_rccl.handle = nullptr; return; }
+    Dl_info info{};
+    if (dladdr(reinterpret_cast<void*>(g_rccl.GetUniqueId), &info) && info.dli_fname) g_lib_path = info.dli_fname;
 }
 
 int need_rccl() {
@@ -94,8 +109,15 @@ int SlabComm::set_transport(int r, int w, smo_alltoall_fn a2a, smo_allreduce_fn 
     return SMO_OK;
 }
 
-SlabComm::~SlabComm() {
+void SlabComm::reset() {
     if (nccl_ && g_rccl.handle) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(nccl_));
+    nccl_ = nullptr; a2a_ = nullptr; ared_ = nullptr; user_ = nullptr;
+}
+SlabComm::~SlabComm() { reset(); }
+
+const char* SlabComm::library_path() {
+    std::call_once(g_once, load_rccl);
+    return g_rccl.handle ? g_lib_path.c_str() : "";
 }
 
 int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s) {

@@ -26,6 +26,10 @@ public:
     // sum over the ranks of n doubles (host values in and out); synchronises `s`.  `dev_scratch`: >= n doubles of device memory
     int allreduce_sum(double* vals, int n, hipStream_t s, double* dev_scratch);
     static int unique_id(void* out128);
+    // drop the transport (ncclCommDestroy / forget the caller's functions): ready() is false again and a new init may follow
+    void reset();
+    // path of the librccl this library bound (dladdr of ncclGetUniqueId; loads it if nobody has yet), "" if none could be loaded
+    static const char* library_path();
 
 private:
     void* nccl_ = nullptr;           // ncclComm_t

@@ -821,7 +821,7 @@ public:
     double *d_U = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     size_t n_part_rows = 1;
-    int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1;
+    int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1, k_ex = -1;
 
     // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time
     int ck = 1, scratch_window = -1;
@@ -989,6 +989,9 @@ public:
         k_zfa = timing.add_class("kd_z_forward<adj_update>", 3 * (S1 + S0) + 12 * S0 + nxt,    // F1 only: F2 is summed on the grid side (nu_B / nu_C)
                                  3 * S1 + 6 * S0 + (cfg.cost == SMO_COST_INTEGRATED ? 3 * S0 : 0.0) + nxt_hbm);
         k_misc = timing.add_class("kd_misc(setup/terminal/energy/grid io)", 0);
+        // slab transposes: HIP events around every grouped send/recv on the stream it is issued on (one field group of one rank, all
+        // peers, as the byte figure; an adjoint step without kept grid states sends two groups in one call)
+        k_ex = timing.add_class("slab_exchange(all-to-all)", 16.0 * tzb * W, 0.0);
         return SMO_OK;
     }
 
@@ -1301,6 +1304,7 @@ public:
         const cplx* src = (to_y ? zs : ys) + off;
         cplx* dst = (to_y ? ys : zs) + off;
         if (!to_y) zs_ready_fwd = zs_ready_adj = -1;
+        ScopedTimer t(timing, k_ex, s);
         return comm.alltoall(src, dst, (size_t)nf * tzc * sizeof(cplx), s);
     }
     enum { ST_FWD = 0, ST_ADJ = 1 };
@@ -1389,15 +1393,28 @@ public:
         have_forward = false;
         return SMO_OK;
     }
+    // a context whose ranks could not agree (different checkpoint intervals, a buffer that would not free, chunks that do not divide)
+    // must not keep a live transport: K, the Ty stack and the Ty cache may then differ between the ranks and the next solve would hang
+    // in a mismatched all-to-all.  The transport is dropped, smo_forward fails with SMO_ERR_STATE, and smo_comm_init may be called again.
+    int attach_or_drop() {
+        const int rc = comm_attach();
+        if (rc != SMO_OK) {
+            const std::string why = last_error();
+            (void)hipStreamSynchronize(stream);
+            comm.reset();
+            set_error("%s (the communicator was dropped: call smo_comm_init / smo_comm_set_transport again once the ranks agree)", why.c_str());
+        }
+        return rc;
+    }
     int comm_init(const void* id128) override {
         if (cfg.world == 1 && !force_exchange) { set_error("smo_comm_init: single-slab context (nothing to exchange)"); return SMO_ERR_STATE; }
         SMO_TRY(comm.init_rccl(cfg.rank, cfg.world, id128));
-        return comm_attach();
+        return attach_or_drop();
     }
     int comm_set_transport(smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user) override {
         if (cfg.world == 1 && !force_exchange) { set_error("smo_comm_set_transport: single-slab context (nothing to exchange)"); return SMO_ERR_STATE; }
         SMO_TRY(comm.set_transport(cfg.rank, cfg.world, a2a, ared, user));
-        return comm_attach();
+        return attach_or_drop();
     }
     double comm_info(int key) const override {
         if (key == 0) return (double)K;

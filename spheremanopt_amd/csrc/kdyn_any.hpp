@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void kda_x_pass(XSpec sp, const double* __res
     cplx* P[3] = {any_lds, any_lds + (size_t)NB * L, any_lds + (size_t)2 * NB * L};      // (the third only in the adjoint pass)
     cplx* tws = any_lds + (size_t)(mode == X_FUSED_ADJ ? 3 : 2) * NB * L;
     any_load_tw(tws, tw, L, tid, NT);
-    // (the lambdas are always inlined: a closure that captures by reference lives in private memory and must not be passed by address)
+    // (the lambdas are always inlined: no kernel of this library may call a device function — csrc/shb23.hip `dct2<0>`)
     // b = c * HP + p; the second line of the last pair is absent when the plane has an odd number of points
     auto ok1 = [&](int p) __attribute__((always_inline)) { return i0 + 2 * p < plane; };
     auto ok2 = [&](int p) __attribute__((always_inline)) { return i0 + 2 * p + 1 < plane; };

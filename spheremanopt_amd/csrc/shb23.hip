@@ -202,9 +202,13 @@ template <> struct DctWork<0> {
     int N;
     AnyPlan pl;
 };
-// (forced inline, like load_tables<0> below: the work area of the any-N form is a kernel-local struct of LDS pointers, and a call that is NOT
-// inlined would hand the callee a flat pointer into the caller's private memory — when the inliner stopped inlining dct3<0> into the
-// Continuous adjoint kernel, that kernel returned garbage and a hand-made out-of-line variant faulted with an aperture violation)
+// Forced inline, like load_tables<0> below and the kernels' lambdas: NO kernel of this library may call a device function.  Out of line,
+// dct3<0> / dct2<0> themselves are fine (flat pointers into the caller's private memory and into LDS, barriers inside the callee, LDS
+// above 64 KB: tools/micro_outline_abi.hip passes on the GPU) — what breaks is the CALLER: under register pressure ROCm 7.2's register
+// allocator (with IPRA) saves the per-lane values that must survive the call (1/dt, N as a double, LDS addresses) by VGPR copies placed
+// AHEAD of the `s_or_b64 exec` that ends the preceding `if (tid < N)` region and copies them back with all lanes on: every masked lane
+// gets garbage (NaN results, or a wild address = the memory fault seen in round 2).  Root-cause analysis, GPU experiments and the static
+// detector: DESIGN.md section 4c, tools/run_outline_abi.sh, tools/scan_exec_masked_saves.py; guard: tests/test_no_device_calls.py.
 // y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N)) = 2 Re(e^{-i pi k/(2N)} V_k),  V = F_N v,  v[j] = x[2j], v[N-1-j] = x[2j+1]
 template <> __device__ __forceinline__ void dct2<0>(DctWork<0>& w, const double* x, double* y, int tid) {
     const int N = w.N;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
     }
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
-    auto to_grid = [&](const double* coeff, double* out) __attribute__((always_inline)) {      // T^-1 of a coefficient vector that is zero beyond Nc (always inlined: the closure must not be passed by address, see dct2<0>)
+    auto to_grid = [&](const double* coeff, double* out) __attribute__((always_inline)) {      // T^-1 of a coefficient vector that is zero beyond Nc (always inlined: no device calls, see dct2<0>)
         for (int k = tid; k < N; k += NT) s.t[k] = (k == 0) ? coeff[0] : ((k & 1) ? -0.5 : 0.5) * coeff[k];
         __syncthreads();
         dct3(s.w, s.t, out, tid);

@@ -87,7 +87,7 @@ struct TimingClass {
 class Timing {
 public:
     bool on = false;
-    int only = -1;                    // -1: time every class; k >= 0: only class k (keeps the event overhead out of the other launches)
+    unsigned long long mask = ~0ull;  // classes whose launches are timed (bit k = class k): keeps the event overhead out of the other launches
     std::vector<TimingClass> cls;
     int add_class(const char* name, double bytes, double hbm = -1.0) {
         cls.push_back({name, bytes, 0, 0.0, hbm < 0 ? bytes : hbm});
@@ -108,7 +108,7 @@ private:
 struct ScopedTimer {
     Timing& t; int k; hipStream_t s;
     bool active;
-    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && (t_.only < 0 || t_.only == k_)) {
+    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && ((t_.mask >> k_) & 1ull)) {
         if (active) t.begin(k, s);
     }
     ~ScopedTimer() { if (active) t.end(k, s); }

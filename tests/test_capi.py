@@ -107,3 +107,35 @@ def _build_c_smoke(tmpdir):
 
 def test_header_is_valid_c_and_a_c_program_links(tmp_path):
     assert os.path.exists(_build_c_smoke(tmp_path))
+
+
+def _run_py(code, env_extra):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(L):
+    """with no loadable librccl, smo_comm_unique_id must return SMO_ERR_UNSUPPORTED with a message (the old loader called
+    dlerror() twice and built a std::string from NULL).  SMO_RCCL_LIB replaces the loader's candidate list; own process because the
+    library is bound once per process."""
+    code = ("import ctypes as C\nfrom spheremanopt_amd import _capi\nL = _capi.lib()\nb = C.create_string_buffer(128)\n"
+            "rc = L.smo_comm_unique_id(b)\nprint('RC', rc, '|', L.smo_last_error().decode(), '|', repr(L.smo_comm_library().decode()))\n")
+    p = _run_py(code, {"SMO_RCCL_LIB": "/nonexistent/librccl-not-here.so"})
+    assert p.returncode == 0, p.stderr
+    line = [l for l in p.stdout.splitlines() if l.startswith("RC")][0]
+    assert line.startswith("RC 6 |"), line                        # SMO_ERR_UNSUPPORTED
+    assert "cannot load librccl" in line and "librccl-not-here.so" in line
+    assert line.rstrip().endswith("''")                            # and no library path is claimed
+
+
+def test_bound_librccl_is_reported(L):
+    """smo_comm_library(): the file the bound ncclGetUniqueId lives in (which of a process' RCCL copies carries the transposes)."""
+    if not os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        pytest.skip("no system librccl")
+    code = ("from spheremanopt_amd import _capi\nprint('LIB', _capi.lib().smo_comm_library().decode())\n")
+    p = _run_py(code, {"SMO_RCCL_LIB": "/opt/rocm/lib/librccl.so.1"})
+    assert p.returncode == 0, p.stderr
+    line = [l for l in p.stdout.splitlines() if l.startswith("LIB")][0]
+    assert "librccl" in line and os.path.exists(line.split(None, 1)[1])
