@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short SH23 / SHB23 lines appended to the default run")
     ap.add_argument("--no-host-vectors", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg of the kdyn workload")
     ap.add_argument("--replicas", action="store_true", help="N>1: run N independent gradients instead of the slab decomposition")
+    ap.add_argument("--allow-replica-fallback", action="store_true", help="N>1: if the slab-decomposed path fails, report independent replicas "
+                    "(flagged in config.slab_path_error) instead of exiting non-zero")
     return ap.parse_args()
 
 
@@ -249,6 +251,15 @@ class _PyLoop:
         self.forward, self.adjoint, self.local_slab = p.forward, p.adjoint, p.local_slab
 
 
+def _rccl_library():
+    """File of the librccl that libsmo bound for its own communicator (smo_comm_library: dladdr of its ncclGetUniqueId)."""
+    from spheremanopt_amd import _capi
+    try:
+        return _capi.lib().smo_comm_library().decode() or None
+    except Exception:
+        return None
+
+
 def _slab_elems(N, world):
     """complex128 elements of ONE field group of one rank's exchange buffer, all peers: 3 * (a/W) * m * G."""
     return 3 * (N // 2 // world) * (N - 1) * (3 * N // 2)
@@ -307,7 +318,9 @@ def _slab_run(torch, N, Rm, dt, n_iters, steps, warm, ckpt=1):
         s.forward([Bl, Ul]); s.adjoint("Discrete", out)
     tim_all = s.ctx.timing() if warm else None
     if tim_all:
-        s.ctx.timing_enable(only=max(range(len(tim_all)), key=lambda i: tim_all[i]["total_ms"] if tim_all[i]["hbm_bytes_per_launch"] > 0 else -1.0))
+        dom_i = max(range(len(tim_all)), key=lambda i: tim_all[i]["total_ms"] if tim_all[i]["hbm_bytes_per_launch"] > 0 else -1.0)
+        ex_i = [i for i, t in enumerate(tim_all) if t["kernel"].startswith("slab_exchange")]
+        s.ctx.timing_enable(select=[dom_i] + ex_i)       # the dominant kernel class + every grouped send/recv (events on the stream it runs on)
     torch.cuda.synchronize()
     torch.distributed.barrier()
     t0 = time.perf_counter()
@@ -318,6 +331,20 @@ def _slab_run(torch, N, Rm, dt, n_iters, steps, warm, ckpt=1):
     el = time.perf_counter() - t0
     s.warmup_timing = tim_all
     return s, J, el
+
+
+def _slab_time_split(s, tim, el, steps, warm, n_iters):
+    """Where a step pair's time goes on this rank: kernels (every class but the exchanges, from the warm-up breakdown, which times every
+    launch) and the transposes (HIP events around every grouped send/recv in the TIMED region, on the stream they run on: with K > 1 chunks
+    they overlap the kernels, so compute + exchange may exceed the wall time per step pair)."""
+    def is_ex(t):
+        return t["kernel"].startswith("slab_exchange")
+    brk = s.warmup_timing or tim
+    ex_t = [t for t in tim if is_ex(t)]
+    return {"compute_ms_per_step_pair": sum(t["total_ms"] for t in brk if not is_ex(t)) / (max(warm, 1) if s.warmup_timing else steps) / n_iters,
+            "exchange_ms_per_step_pair": (sum(t["total_ms"] for t in ex_t) / steps / n_iters) if ex_t and ex_t[0]["launches"] else None,
+            "exchange_calls_per_step_pair": (sum(t["launches"] for t in ex_t) / steps / n_iters) if ex_t else None,
+            "wall_ms_per_step_pair": 1e3 * el / steps / n_iters}
 
 
 def bench_kdyn_slab(a, torch, rank, world):
@@ -350,6 +377,7 @@ def bench_kdyn_slab(a, torch, rank, world):
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     brk = s.warmup_timing or tim                               # per-class breakdown from the warm-up gradients
     brk_wall = (el / steps * max(warm, 1)) if s.warmup_timing else el
+    split = _slab_time_split(s, tim, el, steps, warm, n_iters)
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms, "per_gpu": True,
             "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
@@ -367,6 +395,8 @@ def bench_kdyn_slab(a, torch, rank, world):
                           % (world, {"rccl": "RCCL grouped send/recv", "callback": "callback (host-staged, test only)"}.get(s.transport, s.transport),
                              s.exchanges_per_step_pair, s.K),
            "transport": s.transport, "chunk_autotune_s": getattr(s, "chunk_autotune", None),
+           **split,
+           "rccl_library": _rccl_library() if s.transport == "rccl" else None,
            "exchange_MB_sent_per_gpu_per_step_pair": s.exchanges_per_step_pair * _slab_elems(N, world) * 16 / 1e6 * (world - 1) / world,
            "grid_states_kept_GB_per_gpu": s.ctx.get(1) / 1e9}
     # BASELINE configs[4] rides along when the default workload is run: ONE 256^3 gradient over the same GPUs (not `value`)
@@ -377,9 +407,11 @@ def bench_kdyn_slab(a, torch, rank, world):
         try:
             # ckpt = 0: every rank takes the smallest checkpoint interval whose share of the stack fits its free HBM (2 GPUs: every
             # snapshot fits; the ranks agree on the interval inside smo_comm_init)
-            s2, J2, el2 = _slab_run(torch, big, Rm, dt, n_iters, 1, 0, ckpt=0)
+            st2 = int(os.environ.get("SMO_BENCH_256_STEPS", "2"))
+            s2, J2, el2 = _slab_run(torch, big, Rm, dt, n_iters, st2, 1, ckpt=0)
             cfg["config_256"] = {"workload": "Kinematic dynamo 3D Fourier %d^3 slab-decomposed across %d GPUs, T=%g, dt=%g" % (big, world, dt * n_iters, dt),
-                                 "ms_per_gradient": 1e3 * el2, "gradient_evals_per_s": 1.0 / el2, "steps": 1, "warmup": 0, "J": J2,
+                                 "ms_per_gradient": 1e3 * el2 / st2, "gradient_evals_per_s": st2 / el2, "steps": st2, "warmup": 1, "J": J2,
+                                 **_slab_time_split(s2, s2.ctx.timing(), el2, st2, 1, n_iters),
                                  "stack_GB_per_gpu": s2.ctx.stack_bytes / 1e9, "checkpoint_interval": int(s2.ctx.get(0)),
                                  "chunks": s2.K, "chunk_autotune_s": getattr(s2, "chunk_autotune", None),
                                  "exchange_MB_sent_per_gpu_per_step_pair": s2.exchanges_per_step_pair * _slab_elems(big, world) * 16 / 1e6 * (world - 1) / world}
@@ -412,13 +444,27 @@ def bench_kdyn(a, torch, rank, world):
     # dominant kernel = the byte-moving class with the largest share (the misc class — setup, reductions — has no byte model)
     dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"] if tim[i]["hbm_bytes_per_launch"] > 0 else -1.0)
     share = tim[dom_i]["total_ms"] / tot_ms
+    # THE TIMED REGION.  SURVEY 8d's metric: one f + one Grad_f at the same X "including H2D of X and D2H of grad J" — the callbacks
+    # the reference's optimiser calls hand over host vectors.  On one GPU the timed steps therefore go through the host-buffer entry
+    # points (smo_forward / smo_adjoint on pinned vectors); the device-resident rate (vectors already in HBM: what devvec.DeviceVector
+    # callers get) is measured right after and rides along as config.value_device_vectors.  Replica / slab legs (world > 1, or
+    # --no-host-vectors) time the device-resident form.
+    host_primary = world == 1 and not getattr(a, "no_host_vectors", False)
+    if host_primary:
+        hX = [_capi.pinned_copy(B), _capi.pinned_copy(U)]
+        hG = [_capi.pinned_empty(B.size), _capi.pinned_empty(U.size)]
+        ctx.timing_enable(False)
+        ctx.forward(hX); ctx.adjoint(None, out=hG)           # first touch of the staging path
     ctx.timing_enable(only=dom_i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        J = ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
+        if host_primary:
+            J = ctx.forward(hX); ctx.adjoint(None, out=hG)
+        else:
+            J = ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -463,30 +509,28 @@ def bench_kdyn(a, torch, rank, world):
     roof["whole_gradient_frac"] = roof["whole_gradient_GBps"] / roof["peak"]
     roof["whole_gradient_algorithmic_TB"] = per_grad / 1e12
     roof["whole_gradient_algorithmic_GBps"] = per_grad / (el / steps) / 1e9
-    # SURVEY 8d's metric includes the H2D of X and the D2H of grad J: the same gradient through the host-buffer entry points
-    # (smo_forward / smo_adjoint with pinned host vectors), a few evaluations, reported beside `value`, never as it
-    host = None
-    if world == 1 and not getattr(a, "no_host_vectors", False):
-        hs = max(1, min(steps, 3))
-        hX = [_capi.pinned_copy(B), _capi.pinned_copy(U)]
-        hG = [_capi.pinned_empty(B.size), _capi.pinned_empty(U.size)]
+    # the same gradient with the vectors already resident in HBM (smo_forward_dev / smo_adjoint_dev), a few evaluations: beside `value`
+    dev = None
+    if host_primary:
+        ds = max(1, min(steps, 3))
         ctx.timing_enable(False)
-        ctx.forward(hX); ctx.adjoint(None, out=hG)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(hs):
-            Jh = ctx.forward(hX); ctx.adjoint(None, out=hG)
+        for _ in range(ds):
+            Jd = ctx.forward_dev([Bd, Ud]); ctx.adjoint_dev([Bd, Ud], [gB, gU])
         torch.cuda.synchronize()
-        eh = time.perf_counter() - t1
-        host = {"value": hs / eh, "unit": "gradient evals/s", "ms_per_step": 1e3 * eh / hs, "steps": hs,
-                "J_equal": bool(Jh == J), "note": "smo_forward + smo_adjoint on pinned host vectors: H2D of X (2 x %.0f MB) and D2H of grad J "
-                "(2 x %.0f MB) inside the timed region (SURVEY 8d)" % (B.nbytes / 1e6, B.nbytes / 1e6)}
+        ed = time.perf_counter() - t1
+        dev = {"value": ds / ed, "unit": "gradient evals/s", "ms_per_step": 1e3 * ed / ds, "steps": ds, "J_equal": bool(Jd == J),
+               "grad_equal": bool(np.array_equal(gB.cpu().numpy(), hG[0]) and np.array_equal(gU.cpu().numpy(), hG[1])),
+               "note": "smo_forward_dev + smo_adjoint_dev: X and grad J stay in HBM (no PCIe traffic in the timed steps)"}
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint"
                        % (N, Rm, dt * n_iters, dt),
            "grid": [G_, G_, G_], "n_iters": n_iters, "stack_GB": ctx.stack_bytes / 1e9, "checkpoint_interval": ck, "y_side_stack_GB": ctx.get(1) / 1e9, "J": J,
            "parallelism": "1 GPU" if world == 1 else "replicas only (x%d independent gradients)" % world}
-    if host:
-        cfg["value_host_vectors"] = host
+    cfg["vectors"] = ("host (pinned): H2D of X (2 x %.0f MB) and D2H of grad J (2 x %.0f MB) inside the timed region, SURVEY 8d" % (B.nbytes / 1e6, B.nbytes / 1e6)
+                      if host_primary else "device-resident (HBM)")
+    if dev:
+        cfg["value_device_vectors"] = dev
     # the timed gradient against the committed oracle value for exactly this workload (data under tests/golden/, not oracle code)
     fx = os.path.join(ROOT, "tests", "golden", "oracle_kdyn_c4_%d_n%d.npz" % (N, n_iters))
     if os.path.exists(fx):
@@ -498,8 +542,9 @@ def bench_kdyn(a, torch, rank, world):
             pass
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1)
-        cfg["cpu_all_cores"] = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, os.cpu_count() or 1)
+        ss = getattr(a, "cpu_sample_steps", None) or 4
+        cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1, sample_steps=ss)
+        cfg["cpu_all_cores"] = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, os.cpu_count() or 1, sample_steps=ss)
     return steps, warm, el, 1, roof, cfg, cpu
 
 
@@ -600,8 +645,16 @@ def main():
         # every rank takes the same branch: the slab result stands only if it succeeded everywhere
         flag = torch.tensor([0.0 if slab_err is None else 1.0], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-        if float(flag.item()) > 0:               # keep the contract (one JSON line) even if the slab path fails on this node
-            sys.stderr.write("rank %d: slab path failed (%r); every rank falls back to independent replicas\n" % (rank, slab_err or "on another rank"))
+        if float(flag.item()) > 0:
+            # A scaling driver must never record N independent gradients as if they were one decomposed solve: a failed slab path ends the
+            # job with a non-zero exit code on every rank (no JSON line) unless --allow-replica-fallback asks for the replica line
+            sys.stderr.write("rank %d: slab path failed (%r)%s\n" % (rank, slab_err or "on another rank",
+                             "; every rank falls back to independent replicas" if a.allow_replica_fallback else "; exiting (no fallback without --allow-replica-fallback)"))
+            if not a.allow_replica_fallback:
+                if watchdog is not None:
+                    watchdog.cancel()
+                torch.distributed.destroy_process_group()
+                raise SystemExit(3)
             torch.cuda.empty_cache()
             steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn(a, torch, rank, world)
             cfg["slab_path_error"] = repr(slab_err) if slab_err is not None else "failed on another rank"
@@ -625,15 +678,25 @@ def main():
         if wl == "kdyn" and a.npts is None and a.iters is None:
             try:
                 torch.cuda.empty_cache()
-                b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": 1, "warmup": 0, "no_cpu_baseline": True, "no_host_vectors": True})
-                st, _, e2, _, rf, cf, _ = bench_kdyn(b, torch, rank, world)
-                cfg["config_256"] = {"workload": cf["workload"] + " on 1 GPU", "ms_per_gradient": 1e3 * e2 / st, "gradient_evals_per_s": st / e2,
-                                     "steps": st, "warmup": 0, "J": cf["J"], "stack_GB_per_gpu": cf["stack_GB"],
-                                     "checkpoint_interval": cf["checkpoint_interval"],
-                                     # the same roofline accounting as the main line, for the dominant kernel of the G = 384 instantiations
-                                     "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                                          "avg_launch_ms", "bytes_per_launch", "achieved_algorithmic",
-                                                                          "whole_gradient_GBps", "whole_gradient_frac")}}
+                # warm-up 1, two timed gradients through the host-buffer entry points like the main line, its own CPU leg (a 2-step sample of
+                # the oracle at 256^3, 1 thread and all cores): north_star's "x the CPU baseline on the 256^3 gradient at 1 MI355X" as a number
+                b = argparse.Namespace(**{**vars(a), "npts": 256, "steps": int(os.environ.get("SMO_BENCH_256_STEPS", "2")), "warmup": 1,
+                                          "no_cpu_baseline": a.no_cpu_baseline, "cpu_sample_steps": 2})
+                st, wm, e2, _, rf, cf, cpu2 = bench_kdyn(b, torch, rank, world)
+                c256 = {"workload": cf["workload"] + " on 1 GPU", "ms_per_gradient": 1e3 * e2 / st, "gradient_evals_per_s": st / e2,
+                        "steps": st, "warmup": wm, "J": cf["J"], "stack_GB_per_gpu": cf["stack_GB"], "vectors": cf["vectors"],
+                        "checkpoint_interval": cf["checkpoint_interval"], "value_device_vectors": cf.get("value_device_vectors"),
+                        # the same roofline accounting as the main line, for the dominant kernel of the G = 384 instantiations
+                        "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                             "avg_launch_ms", "bytes_per_launch", "achieved_algorithmic",
+                                                             "whole_gradient_GBps", "whole_gradient_frac")}}
+                if cpu2:
+                    c256["cpu_baseline"] = cpu2
+                    c256["cpu_all_cores"] = cf.get("cpu_all_cores")
+                    c256["speedup_vs_cpu_1_core"] = c256["gradient_evals_per_s"] / cpu2["value"]
+                    if cf.get("cpu_all_cores"):
+                        c256["speedup_vs_cpu_all_cores"] = c256["gradient_evals_per_s"] / cf["cpu_all_cores"]["value"]
+                cfg["config_256"] = c256
             except Exception as e:                   # never lose the main line because of the extra
                 cfg["config_256"] = {"error": repr(e)}
     if world > 1:
@@ -644,7 +707,7 @@ def main():
     if rank == 0:
         total = steps * per_step_units * world
         out = {"metric": "forward+adjoint gradient evals/sec", "value": total / el, "unit": "gradient evals/s",
-               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.get_backend() == "nccl") else (1 if world == 1 else 0)),
+               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.get_backend() == "nccl") else 0),      # 0: no RCCL communicator exists in this run
                "backend": (torch.distributed.get_backend() if world > 1 else None),
                "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,

@@ -206,8 +206,9 @@ template <> struct DctWork<0> {
 // dct3<0> / dct2<0> themselves are fine (flat pointers into the caller's private memory and into LDS, barriers inside the callee, LDS
 // above 64 KB: tools/micro_outline_abi.hip passes on the GPU) — what breaks is the CALLER: under register pressure ROCm 7.2's register
 // allocator (with IPRA) saves the per-lane values that must survive the call (1/dt, N as a double, LDS addresses) by VGPR copies placed
-// AHEAD of the `s_or_b64 exec` that ends the preceding `if (tid < N)` region and copies them back with all lanes on: every masked lane
-// gets garbage (NaN results, or a wild address = the memory fault seen in round 2).  Root-cause analysis, GPU experiments and the static
+// AHEAD of the `s_or_b64 exec` that ends the preceding `for (k = tid; k < N; k += NT)` region — i.e. with the tid < N lanes or, coming from the
+// loop's exit, with NO lane enabled — and copies them back with all lanes on: garbage in every lane (NaN results, or a wild address = the
+// memory fault seen in round 2).  Root-cause analysis, GPU experiments and the static
 // detector: DESIGN.md section 4c, tools/run_outline_abi.sh, tools/scan_exec_masked_saves.py; guard: tests/test_no_device_calls.py.
 // y[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N)) = 2 Re(e^{-i pi k/(2N)} V_k),  V = F_N v,  v[j] = x[2j], v[N-1-j] = x[2j+1]
 template <> __device__ __forceinline__ void dct2<0>(DctWork<0>& w, const double* x, double* y, int tid) {

@@ -3,9 +3,10 @@
 
 ROCm 7.2's hipcc (gfx950), given a kernel that CALLS a device function, splits the live ranges of the values that must survive the call:
 VGPR copies into call-preserved registers before the call, copies back after it.  It places the saving copies at the top of the block
-that joins an `if (tid < N)` region — BEFORE the `s_or_b64 exec, exec, sX` that re-enables the lanes the region had masked off — while
-the copies back run with all lanes on.  Lanes that were masked (whole waves when N < the workgroup size) get garbage for per-lane values
-(1/dt, N as a double, LDS addresses): NaNs, wrong results, or a memory fault from a wild address.
+that follows a `for (k = tid; k < N; k += NT)` region — BEFORE the `s_or_b64 exec, exec, sX` that re-enables the lanes — while the copies back run
+with all lanes on.  That block is reached with the `tid < N` subset of the lanes or, from the loop's exit, with NO lane (a divergent loop leaves
+exec = 0 until the restore): the saves store nothing and every lane gets garbage for per-lane values (1/dt, N as a double, LDS addresses):
+NaNs, wrong results, or a memory fault from a wild address.
 
 The scan: in the disassembly of every gfx950 code object of a library, for every `s_*_saveexec_b64 sX` / `s_xor_b64 sX, exec, ..` followed
 by `s_cbranch_execz L`, look at block L up to its `s_or_b64 exec, exec, sX`; any instruction in between that writes a VGPR is such a
