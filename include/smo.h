@@ -94,6 +94,19 @@ typedef struct smo_config {
 
 /* ---- life cycle ------------------------------------------------------------------------------------------- */
 int         smo_create(const smo_config* cfg, smo_ctx** out);
+/* ONE host process driving several GPUs of a node ("one host process driving the devices").  The reference's optimiser is a
+ * single Python process; under `mpiexec -np P` every rank runs it redundantly and Dedalus moves the data (README.md:83, FWD_Solve_KDyn.py:118-134).
+ * A multi-device context slab-decomposes a KDYN problem over `ndev` devices (cfg->rank / world stay 0 / 1, cfg->device is ignored; ndev must
+ * divide npts/2 and 3*npts/2) behind the single-GPU calling sequence:
+ *   smo_forward / smo_adjoint / smo_inner  take the reference's FULL flat host vectors [3][G][G][G] and return the full gradient: the library
+ *       scatters / gathers the z slabs itself (the allgather of Field_to_Vec, FWD_Solve_KDyn.py:118-123, disappears);
+ *   smo_forward_dev / smo_adjoint_dev      take ndev slab pointers per component instead: X[c * ndev + i] = component c's slab
+ *       [3][G][G][G/ndev] in the HBM of dev_ids[i];
+ * inside, one worker thread per device runs the same in-library time loop as with one process per GPU, and a transpose is every device pulling
+ * its blocks from its peers with hipMemcpyPeerAsync (peer access over xGMI), ordered by HIP events — no RCCL, no launcher, nothing for the
+ * caller to set up.  The same device may be listed more than once (tests on a one-GPU box).  smo_snapshot_read and smo_inner_dev are not
+ * available on such a context; smo_timing_* report device 0's kernels. */
+int         smo_create_multi(const smo_config* cfg, int ndev, const int* dev_ids, smo_ctx** out);
 void        smo_destroy(smo_ctx* ctx);
 const char* smo_last_error(void);
 const char* smo_version(void);
@@ -106,7 +119,8 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by t
 /* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: KDYN: bytes of the y-side stack kept by the forward
  * solve so that the adjoint skips the z/y passes of every snapshot (0 if not in use); SHB23: how many calls fell back from the
  * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU);  key 2 (KDYN): number of
- * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch). */
+ * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch);
+ * key 3 (KDYN): layout of the y-transformed work fields, 0 = planes [c][kx][y][z], 1 = z-block major [c][z/8][kx][y][z%8]. */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */

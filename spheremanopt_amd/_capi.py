@@ -19,7 +19,7 @@ ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO
              6: "SMO_ERR_UNSUPPORTED"}
 
 EXPORTS = [
-    "smo_create", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
+    "smo_create", "smo_create_multi", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
     "smo_stack_bytes", "smo_get", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
     "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get", "smo_timing_hbm_bytes",
     "smo_vec_alloc", "smo_vec_free", "smo_vec_pool_release", "smo_vec_pool_bytes", "smo_vec_upload", "smo_vec_download", "smo_vec_axpby",
@@ -79,6 +79,7 @@ def lib():
     L.smo_version.restype = C.c_char_p
     L.smo_device_count.argtypes = [ip]
     L.smo_create.argtypes = [C.POINTER(smo_config), pp]
+    L.smo_create_multi.argtypes = [C.POINTER(smo_config), C.c_int, ip, pp]
     L.smo_destroy.argtypes = [vp]
     L.smo_destroy.restype = None
     L.smo_ncomp.argtypes = [vp]
@@ -201,6 +202,7 @@ def pinned_copy(x):
 
 class Context:
     """Owner of one smo_ctx (device buffers, twiddles, the HBM snapshot stack)."""
+    devices = None          # MultiContext: the device list
 
     def __init__(self, kind, npts, interval, dt, n_iters, param, cost="Final", batch=1, device=0, rank=0, world=1, ckpt=1,
                  npts2=0, param2=0., param3=0., param4=0.):
@@ -210,6 +212,10 @@ class Context:
         self.cfg = cfg
         self._h = C.c_void_p()
         _check(lib().smo_create(C.byref(cfg), C.byref(self._h)))
+        self._describe()
+        self.batch = int(batch)
+
+    def _describe(self):
         self.ncomp = lib().smo_ncomp(self._h)
         n = C.c_size_t()
         _check(lib().smo_vec_len(self._h, C.byref(n)))
@@ -218,7 +224,6 @@ class Context:
         self.stack_bytes = n.value
         _check(lib().smo_snapshot_len(self._h, C.byref(n)))
         self.snapshot_len = n.value
-        self.batch = int(batch)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -416,3 +421,25 @@ class Context:
             res.append({"kernel": name.value.decode(), "launches": n.value, "total_ms": ms.value, "bytes_per_launch": by.value,
                         "hbm_bytes_per_launch": hb.value})
         return res
+
+
+class MultiContext(Context):
+    """smo_create_multi: ONE process, ONE context, a KDYN problem slab-decomposed over `devices` (include/smo.h).  forward / adjoint / inner take
+    and return the reference's FULL flat vectors like the single-GPU Context; forward_dev / adjoint_dev take one slab pointer per (component,
+    device), component-major."""
+
+    def __init__(self, npts, interval, dt, n_iters, Rm, devices, cost="Final", ckpt=1):
+        cfg = smo_config(SMO_KDYN, int(npts), float(interval[0]), float(interval[1]), float(dt), int(n_iters), float(Rm),
+                         COST[cost] if isinstance(cost, str) else int(cost), 1, int(devices[0]), 0, 1, int(ckpt), 0, 0., 0., 0.)
+        self.cfg = cfg
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        _check(lib().smo_create_multi(C.byref(cfg), len(self.devices), ids, C.byref(self._h)))
+        self._describe()
+        self.batch = 1
+
+    def _check_dev(self, vecs, who):           # per-device slab pointers: ncomp * ndev of them (lengths are the caller's business)
+        want = (2 if who == "inner" else self.ncomp) * len(self.devices)
+        if len(vecs) != want:
+            raise ValueError("%s: %d slab pointers given, %d components x %d devices expected" % (who, len(vecs), self.ncomp, len(self.devices)))

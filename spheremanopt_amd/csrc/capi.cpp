@@ -53,6 +53,20 @@ int smo_create(const smo_config* cfg, smo_ctx** out) {
     return SMO_OK;
 }
 
+int smo_create_multi(const smo_config* cfg, int ndev, const int* dev_ids, smo_ctx** out) {
+    if (!cfg || !out || !dev_ids) { smo::set_error("smo_create_multi: null argument"); return SMO_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->batch != 1 || cfg->n_iters < 1 || cfg->npts < 4 || !(cfg->dt > 0) || !(cfg->x1 > cfg->x0) || cfg->ckpt < 0 || ndev < 1 || ndev > 64) {
+        smo::set_error("smo_create_multi: bad config (npts=%d n_iters=%d dt=%g batch=%d ndev=%d)", cfg->npts, cfg->n_iters, cfg->dt, cfg->batch, ndev);
+        return SMO_ERR_ARG;
+    }
+    Context* c = smo::make_multi(*cfg, ndev, dev_ids);
+    int rc = c->init();
+    if (rc != SMO_OK) { delete c; return rc; }
+    *out = new smo_ctx{c};
+    return SMO_OK;
+}
+
 void smo_destroy(smo_ctx* ctx) {
     if (!ctx) return;
     if (ctx->impl) {
@@ -79,7 +93,7 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes) {
 
 int smo_get(const smo_ctx* ctx, int key, double* value) {
     CHECK_CTX(ctx);
-    if (!value || key < 0 || key > 2) { smo::set_error("smo_get: bad argument"); return SMO_ERR_ARG; }
+    if (!value || key < 0 || key > 3) { smo::set_error("smo_get: bad argument"); return SMO_ERR_ARG; }
     *value = ctx->impl->info(key);
     return SMO_OK;
 }
@@ -201,25 +215,24 @@ int smo_set_stream(smo_ctx* ctx, void* hip_stream) {
 
 int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
-    ctx->impl->timing.reset();
-    ctx->impl->timing.on = (on != 0);
-    ctx->impl->timing.mask = (on >= 2) ? (1ull << (on - 2)) : ~0ull;
+    ctx->impl->tm().reset();
+    ctx->impl->tm().on = (on != 0);
+    ctx->impl->tm().mask = (on >= 2) ? (1ull << (on - 2)) : ~0ull;
     return SMO_OK;
 }
 int smo_timing_select(smo_ctx* ctx, unsigned long long class_mask) {
     CHECK_CTX(ctx);
-    ctx->impl->timing.reset();
-    ctx->impl->timing.on = (class_mask != 0);
-    ctx->impl->timing.mask = class_mask;
+    ctx->impl->tm().reset();
+    ctx->impl->tm().on = (class_mask != 0);
+    ctx->impl->tm().mask = class_mask;
     return SMO_OK;
 }
-int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->timing.cls.size() : 0; }
+int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->tm().cls.size() : 0; }
 int smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms, double* bytes_per_launch) {
     CHECK_CTX(ctx);
-    auto& t = ctx->impl->timing;
+    auto& t = ctx->impl->tm();
     if (k < 0 || k >= (int)t.cls.size()) { smo::set_error("smo_timing_get: class %d", k); return SMO_ERR_ARG; }
-    (void)hipSetDevice(ctx->impl->cfg.device);
-    (void)hipStreamSynchronize(ctx->impl->stream);
+    (void)ctx->impl->sync_all();
     t.flush();
     if (name) *name = t.cls[k].name.c_str();
     if (launches) *launches = t.cls[k].launches;
@@ -229,7 +242,7 @@ int smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, 
 }
 int smo_timing_hbm_bytes(smo_ctx* ctx, int k, double* bytes_per_launch) {
     CHECK_CTX(ctx);
-    auto& t = ctx->impl->timing;
+    auto& t = ctx->impl->tm();
     if (k < 0 || k >= (int)t.cls.size() || !bytes_per_launch) { smo::set_error("smo_timing_hbm_bytes: class %d", k); return SMO_ERR_ARG; }
     *bytes_per_launch = t.cls[k].hbm_bytes;
     return SMO_OK;

@@ -111,7 +111,92 @@ int SlabComm::set_transport(int r, int w, smo_alltoall_fn a2a, smo_allreduce_fn 
 
 void SlabComm::reset() {
     if (nccl_ && g_rccl.handle) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(nccl_));
-    nccl_ = nullptr; a2a_ = nullptr; ared_ = nullptr; user_ = nullptr;
+    nccl_ = nullptr; a2a_ = nullptr; ared_ = nullptr; user_ = nullptr; peers_ = nullptr;
+}
+
+int SlabComm::set_peers(int r, PeerGroup* g) {
+    if (!g) { set_error("set_peers: null group"); return SMO_ERR_ARG; }
+    if (ready()) { set_error("set_peers: the context already has a communicator"); return SMO_ERR_STATE; }
+    peers_ = g; rank = r; world = g->world();
+    return SMO_OK;
+}
+
+// ---- PeerGroup: ranks = threads of one process, one GPU each ---------------------------------------------------------------
+PeerGroup::PeerGroup(const std::vector<int>& devices) : dev(devices) {
+    const int W = (int)dev.size();
+    pub_src.assign(W, nullptr); pub_dst.assign(W, nullptr);
+    ev_ready.assign(W, nullptr); ev_pulled.assign(W, nullptr);
+    red.assign((size_t)W * 64, 0.0);
+    peer_access = true;
+    for (int r = 0; r < W; ++r) {
+        if (hipSetDevice(dev[r]) != hipSuccess) { peer_access = false; continue; }
+        (void)hipEventCreateWithFlags(&ev_ready[r], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev_pulled[r], hipEventDisableTiming);
+        for (int p = 0; p < W; ++p) {
+            if (dev[p] == dev[r]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dev[r], dev[p]) != hipSuccess || !can) { peer_access = false; continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(dev[p], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_access = false;
+            (void)hipGetLastError();
+        }
+    }
+}
+PeerGroup::~PeerGroup() {
+    for (size_t r = 0; r < dev.size(); ++r) {
+        (void)hipSetDevice(dev[r]);
+        if (ev_ready[r]) (void)hipEventDestroy(ev_ready[r]);
+        if (ev_pulled[r]) (void)hipEventDestroy(ev_pulled[r]);
+    }
+}
+int PeerGroup::barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) { set_error("another rank of the multi-device context failed"); return SMO_ERR_STATE; }
+    const unsigned long gen = generation;
+    if (++waiting == world()) { waiting = 0; ++generation; cv.notify_all(); return SMO_OK; }
+    cv.wait(lk, [&] { return generation != gen || failed; });
+    if (generation == gen) { set_error("another rank of the multi-device context failed"); return SMO_ERR_STATE; }
+    return SMO_OK;
+}
+void PeerGroup::abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
+}
+void PeerGroup::reset() {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = false; waiting = 0;
+}
+int PeerGroup::alltoall(int rank, const void* src, void* dst, size_t bytes, hipStream_t s) {
+    const int W = world();
+    pub_src[rank] = src; pub_dst[rank] = dst;
+    SMO_HIP(hipEventRecord(ev_ready[rank], s));
+    SMO_TRY(barrier());
+    for (int q = 0; q < W; ++q) {
+        const int p = (rank + q) % W;                        // start with my own block, then walk the ring: the peers pull from different sources
+        if (p != rank) SMO_HIP(hipStreamWaitEvent(s, ev_ready[p], 0));
+        const char* from = static_cast<const char*>(pub_src[p]) + (size_t)rank * bytes;
+        char* to = static_cast<char*>(dst) + (size_t)p * bytes;
+        if (dev[p] == dev[rank]) SMO_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
+        else SMO_HIP(hipMemcpyPeerAsync(to, dev[rank], from, dev[p], bytes, s));
+    }
+    SMO_HIP(hipEventRecord(ev_pulled[rank], s));
+    SMO_TRY(barrier());
+    for (int p = 0; p < W; ++p)
+        if (p != rank) SMO_HIP(hipStreamWaitEvent(s, ev_pulled[p], 0));
+    return SMO_OK;
+}
+int PeerGroup::allreduce_sum(int rank, double* vals, int n, hipStream_t s) {
+    if (n > 64) { set_error("PeerGroup::allreduce_sum: at most 64 values"); return SMO_ERR_ARG; }
+    SMO_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) red[(size_t)rank * 64 + i] = vals[i];
+    SMO_TRY(barrier());
+    for (int i = 0; i < n; ++i) {
+        double a = 0.0;
+        for (int p = 0; p < world(); ++p) a += red[(size_t)p * 64 + i];      // the same order on every rank: identical sums
+        vals[i] = a;
+    }
+    return barrier();                                        // nobody overwrites its slot before everyone has read it
 }
 SlabComm::~SlabComm() { reset(); }
 
@@ -121,6 +206,7 @@ const char* SlabComm::library_path() {
 }
 
 int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s) {
+    if (peers_) return peers_->alltoall(rank, src, dst, bytes_per_peer, s);
     if (nccl_) {
         ncclComm_t c = static_cast<ncclComm_t>(nccl_);
         const size_t cnt = bytes_per_peer / sizeof(double);
@@ -142,6 +228,7 @@ int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStr
 }
 
 int SlabComm::allreduce_sum(double* vals, int n, hipStream_t s, double* dev_scratch) {
+    if (peers_) return peers_->allreduce_sum(rank, vals, n, s);
     if (nccl_) {
         ncclComm_t c = static_cast<ncclComm_t>(nccl_);
         SMO_HIP(hipMemcpyAsync(dev_scratch, vals, n * sizeof(double), hipMemcpyHostToDevice, s));

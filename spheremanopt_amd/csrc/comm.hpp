@@ -11,13 +11,53 @@
 #pragma once
 #include "smo_common.hpp"
 
+#include <condition_variable>
+#include <mutex>
+
 namespace smo {
+
+// Third transport: the ranks are contexts of ONE process, each driven by its own host thread on its own GPU (smo_create_multi, csrc/multi.cpp).
+// A transpose is then W pulls per rank over the node's point-to-point links, hipMemcpyPeerAsync from every peer's send buffer on the rank's
+// own stream, ordered by HIP events — no RCCL, no second process:
+//   rank r:  publish (src, dst), record ev_ready[r] on its stream           (everything enqueued so far: src produced, dst consumed)
+//            -- host barrier: every rank has recorded --
+//            for every peer p: wait ev_ready[p]; copy p's block for me (src_p + r * bytes, device p) -> dst + p * bytes
+//            record ev_pulled[r]
+//            -- host barrier --
+//            wait ev_pulled[p] of every peer: from here on my src may be overwritten
+// The host barriers only order the *calls* (an event must have been recorded before another thread may wait for it); the data dependencies
+// stay on the GPUs.  A rank that fails raises `failed` and releases the others, so a collective never hangs the process.
+class PeerGroup {
+public:
+    explicit PeerGroup(const std::vector<int>& devices);
+    ~PeerGroup();
+    int world() const { return (int)dev.size(); }
+    int alltoall(int rank, const void* src, void* dst, size_t bytes_per_peer, hipStream_t s);
+    int allreduce_sum(int rank, double* vals, int n, hipStream_t s);
+    void abort();                       // a rank failed outside a collective: release everybody waiting in one
+    void reset();                       // before a new collective call sequence (all ranks idle)
+    std::vector<int> dev;
+    bool peer_access = false;           // hipDeviceEnablePeerAccess succeeded for every pair of distinct devices
+
+private:
+    int barrier();                      // SMO_OK, or SMO_ERR_STATE when a rank has failed
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned long generation = 0;
+    bool failed = false;
+    std::vector<const void*> pub_src;
+    std::vector<void*> pub_dst;
+    std::vector<hipEvent_t> ev_ready, ev_pulled;
+    std::vector<double> red;            // [rank][64]
+};
 
 class SlabComm {
 public:
     int rank = 0, world = 1;
     ~SlabComm();
-    bool ready() const { return nccl_ != nullptr || a2a_ != nullptr; }
+    bool ready() const { return nccl_ != nullptr || a2a_ != nullptr || peers_ != nullptr; }
+    int set_peers(int rank, PeerGroup* g);
     bool is_rccl() const { return nccl_ != nullptr; }
     int init_rccl(int rank, int world, const void* unique_id);
     int set_transport(int rank, int world, smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user);
@@ -36,6 +76,7 @@ private:
     smo_alltoall_fn a2a_ = nullptr;
     smo_allreduce_fn ared_ = nullptr;
     void* user_ = nullptr;
+    PeerGroup* peers_ = nullptr;     // not owned
 };
 
 }  // namespace smo

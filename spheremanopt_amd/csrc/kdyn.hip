@@ -48,6 +48,9 @@ struct Geom {
     size_t typ;   // Ty: elements between consecutive (component, kx) planes (G * Gzl + padding; the padding keeps the x pass's 3a
                   // runs per tile off a power-of-two stride)
     int utile;    // x pass spectrum -> grid: 1 = write the tile-major layout of the internal U field (u_off), 0 = the flat X layout
+    int tyl;      // layout of Ty: 0 = planes [c][kx][y][z] (+ padding per plane), 1 = z-block major [c][z/8][kx][y][z%8] (below)
+    int ykx;      // y pass, z-block-major Ty: 1 = consecutive workgroups take consecutive kx (their G*128-byte blocks are adjacent)
+    size_t tyk;   // z-block major: elements between consecutive kx blocks (8 G + one 128-byte line of padding)
     double Rm, dt;
 };
 
@@ -79,9 +82,31 @@ __device__ __forceinline__ size_t ys_row0(int c, int kx, const Geom& g) {
     const int q = kx / g.al;
     return (size_t)q * g.blk + ((size_t)c * g.al + (kx - q * g.al)) * ((size_t)g.m * g.Gzl);
 }
-// x pass: offset of mode kx (global) of component c, flat local (y,z) index i, in Ty[3][a][G*Gzl]
+// x pass: offset of mode kx (global) of component c, flat local (y,z) index i, in Ty[3][a][G*Gzl] (the plane layout; the run-time-length
+// kernels of kdyn_any.hpp use only this one)
 __device__ __forceinline__ size_t tx_off(int c, int kx, size_t i, const Geom& g) {
     return ((size_t)c * g.a + kx) * g.typ + i;
+}
+// Z-block-major Ty (round 3), Ty[c][z/8][kx][y][z%8], kx blocks G*8 + 8 elements apart.  In the plane layout a fused x-pass tile gathers one
+// 64...128-byte run from each of 3a planes 16*G*Gzl bytes apart (2.4 MB at G = 384) and a y-pass workgroup G lines 16*Gzl bytes apart; here the
+// x-pass runs of a tile lie G*128 + 128 bytes apart inside ONE window of a*(G*128 + 128) bytes per component (6.3 MB at G = 384; the extra line
+// keeps them off one HBM channel, like the plane padding) and a y-pass workgroup (c, kx, 8 z columns) owns one contiguous G*128-byte block.
+// tools/micro_patch_layout.hip, G = 384, same box: x pattern 4.95 -> 5.35 TB/s (tiles walked y-fastest inside a z block), y pattern 5.44 ->
+// 5.63 TB/s (workgroups kx-fastest); 8x8 patches 5.36 / 5.22, row blocks 5.47 / 4.88; without the padding 4.17-4.33 (channel camping).
+__device__ __forceinline__ size_t ty_off(int c, int kx, size_t i, const Geom& g) {      // any flat index i (one division: setup passes only)
+    if (g.tyl == 0) return tx_off(c, kx, i, g);
+    const size_t y = i / g.Gzl;
+    const int z = (int)(i - y * g.Gzl);
+    return (((size_t)c * (g.Gzl >> 3) + (z >> 3)) * g.a + kx) * g.tyk + y * 8 + (z & 7);
+}
+// the fused x passes: a tile of T <= 8 points starting at i0 (a multiple of T) lies inside one z block, so
+//   offset(c, kx, i0 + e) = base + c * cs + kx * ks + e
+struct XOrigin { size_t base, cs, ks; };
+__device__ __forceinline__ XOrigin x_origin(size_t i0, const Geom& g) {
+    if (g.tyl == 0) return XOrigin{i0, (size_t)g.a * g.typ, g.typ};
+    const size_t y = i0 / g.Gzl;
+    const int z0 = (int)(i0 - y * g.Gzl);
+    return XOrigin{(size_t)(z0 >> 3) * g.a * g.tyk + y * 8 + (z0 & 7), (size_t)(g.Gzl >> 3) * g.a * g.tyk, g.tyk};
 }
 
 // The velocity field U is only ever read by the fused x passes, one (y,z) tile per workgroup, all x.  It is therefore kept
@@ -311,10 +336,20 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
     __syncthreads();
     const int ntile = (g.Gzl + ZT - 1) / ZT;
-    const int o = blockIdx.x / ntile, z0 = (blockIdx.x - o * ntile) * ZT;      // o = c * a + kx
-    const int c = o / g.a, kx = o - c * g.a;
+    int c, kx, z0;
+    if (g.tyl && g.ykx) {                       // consecutive workgroups: consecutive kx of one (c, z tile) — adjacent blocks of Ty
+        kx = blockIdx.x % g.a;
+        const int r = blockIdx.x / g.a;
+        c = r / ntile; z0 = (r - c * ntile) * ZT;
+    } else {
+        const int o = blockIdx.x / ntile;       // o = c * a + kx
+        z0 = (blockIdx.x - o * ntile) * ZT;
+        c = o / g.a; kx = o - c * g.a;
+    }
     const size_t zrow = ys_row0(c, kx, g) + z0;                               // + idx * Gzl + b
-    const size_t trow = (size_t)o * g.typ + z0;                                // + y * Gzl + b
+    // Ty side: + y * tys + b
+    const size_t trow = g.tyl ? (((size_t)c * (g.Gzl >> 3) + (z0 >> 3)) * g.a + kx) * g.tyk + (z0 & 7) : ((size_t)c * g.a + kx) * g.typ + z0;
+    const size_t tys = g.tyl ? 8 : (size_t)g.Gzl;
     if (INV) {
         auto ld0 = [&](int b, int pos) -> cplx {
             const int idx = wrap_pos(pos, g);
@@ -322,13 +357,13 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
             return in[zrow + (size_t)idx * g.Gzl + b];
         };
         auto stN = [&](int b, int pos, cplx v) {
-            if (z0 + b < g.Gzl) out[trow + (size_t)pos * g.Gzl + b] = v;
+            if (z0 + b < g.Gzl) out[trow + (size_t)pos * tys + b] = v;
         };
         fft_inplace_ix<L, true, ZT, NT, true, false, false>(buf, ix, tw, tid, ld0, stN);
     } else {
         auto ld0 = [&](int b, int pos) -> cplx {
             if (z0 + b >= g.Gzl) return mk(0, 0);
-            return in[trow + (size_t)pos * g.Gzl + b];
+            return in[trow + (size_t)pos * tys + b];
         };
         auto stN = [&](int b, int pos, cplx v) {
             const int idx = wrap_pos(pos, g);
@@ -378,6 +413,12 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     const size_t plane = (size_t)g.G * g.Gzl;       // local (y,z) points
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
+    // offset in Ty of (component c, mode kx, line pair p of this tile): tiles of up to 8 points lie inside one z block of either layout
+    const XOrigin xo = x_origin(i0, g);
+    auto spec_off = [&](int c, int kx, int p) -> size_t {
+        if constexpr (T <= 8) return xo.base + c * xo.cs + kx * xo.ks + 2 * p;
+        else return ty_off(c, kx, i0 + 2 * p, g);
+    };
 
     // -- load (spectrum, Hermitian extension) or (grid, two real lines) ------------------------------------------
     auto ld_spec = [&](int b, int pos) -> cplx {
@@ -388,7 +429,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         if (pos < g.a) { kx = pos; cj = false; }
         else if (pos > g.G - g.a) { kx = g.G - pos; cj = true; }
         else return mk(0, 0);
-        const size_t off = tx_off(c, kx, i0 + 2 * p, g);
+        const size_t off = spec_off(c, kx, p);
         cplx X1 = src[off], X2 = src[off + 1];
         if (kx == 0) return mk(X1.re, X2.re);                       // c2r ignores the imaginary part of kx = 0
         if (cj) return mk(X1.re + X2.im, X2.re - X1.im);            // conj(X1) + i conj(X2)
@@ -431,7 +472,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
             const int p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3), c = fc % 3, f = fc / 3;
             cplx X1 = mk(0, 0), X2 = mk(0, 0);
             if (line_ok(p)) {
-                const cplx* src = ((f == 0) ? sp.inA : sp.inB) + tx_off(c, kx, i0 + 2 * p, g);
+                const cplx* src = ((f == 0) ? sp.inA : sp.inB) + spec_off(c, kx, p);
                 // (forward pass, tiles of whole 128-byte lines: its input spectrum is dead once read — non-temporal, so that the hit does not renew it)
                 constexpr bool NTIN = (SMO_X_NT & 16) != 0 && MODE == X_FUSED_FWD && T >= 8;
                 X1 = ld_cplx<NTIN>(src); X2 = ld_cplx<NTIN>(src + 1);
@@ -520,7 +561,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                 for (int i = 0; i < SCNT; ++i) {
                     const int t = tid + i * NT, p = t % HP, r = t / HP, fc = r % (NF * 3), kx = r / (NF * 3);
                     if (t < (L / 3) * NF * 3 * HP && fc >= 3 && line_ok(p)) {
-                        const cplx* q = sp.outB + tx_off(fc - 3, kx, i0 + 2 * p, g);
+                        const cplx* q = sp.outB + spec_off(fc - 3, kx, p);
                         old_sum[i][0] = q[0]; old_sum[i][1] = q[1];
                     }
                 }
@@ -538,7 +579,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         const int c = fc % 3, f = fc / 3;
         const cplx Zk = buf[ix(fc * HP + p, kx)];
         const cplx Zm = conj(buf[ix(fc * HP + p, (kx == 0) ? 0 : L - kx)]);
-        cplx* dst = ((f == 0) ? sp.outA : sp.outB) + tx_off(c, kx, i0 + 2 * p, g);
+        cplx* dst = ((f == 0) ? sp.outA : sp.outB) + spec_off(c, kx, p);
         cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
         if (ACC && f == 1) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
         dst[0] = v0;
@@ -568,6 +609,9 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     const size_t plane = (size_t)g.G * g.Gzl;
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
     auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
+    static_assert(T <= 8, "a tile lies inside one z block of Ty");
+    const XOrigin xo = x_origin(i0, g);
+    auto spec_off = [&](int c, int kx, int p) -> size_t { return xo.base + c * xo.cs + kx * xo.ks + 2 * p; };
 
     auto stage_in = [&](const cplx* src, auto ntl) {           // spectra of one field group -> Hermitian-extended lines in the tile
 #pragma unroll
@@ -576,7 +620,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
             if (t >= NITEM) break;
             const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
             cplx X1 = mk(0, 0), X2 = mk(0, 0);
-            if (line_ok(p)) { const cplx* q = src + tx_off(c, kx, i0 + 2 * p, g); X1 = ld_cplx<decltype(ntl)::value>(q); X2 = ld_cplx<decltype(ntl)::value>(q + 1); }
+            if (line_ok(p)) { const cplx* q = src + spec_off(c, kx, p); X1 = ld_cplx<decltype(ntl)::value>(q); X2 = ld_cplx<decltype(ntl)::value>(q + 1); }
             const int b = c * HP + p;
             if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);
             else {
@@ -613,15 +657,20 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
             buf[ix(b, 3 * j + 2)] = twmul<false>(v[2], tw[2 * j]);
         }
     };
-    cplx old_sum[SCNT][2];
+    // SMO_X_SEQ_LATE_SUM=1 (experiment): read the running sum in the store loop instead of requesting it before the last stage (24 VGPRs less
+    // at the register peak, the latency no longer hidden behind that stage)
+#ifndef SMO_X_SEQ_LATE_SUM
+#define SMO_X_SEQ_LATE_SUM 0
+#endif
+    cplx old_sum[SMO_X_SEQ_LATE_SUM ? 1 : SCNT][2];
     auto forward_and_store = [&](cplx* dst, const bool acc) {
         InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
-            if (acc) {
+            if (acc && !SMO_X_SEQ_LATE_SUM) {
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
                     const int t = tid + i * NT, p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
                     if (t < NITEM && line_ok(p)) {
-                        const cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g);
+                        const cplx* q = dst + spec_off(c, kx, p);
                         old_sum[i][0] = ld_cplx<(SMO_X_NT & 4) != 0>(q); old_sum[i][1] = ld_cplx<(SMO_X_NT & 4) != 0>(q + 1);
                     }
                 }
@@ -636,9 +685,10 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
             if (!line_ok(p)) continue;
             const cplx Zk = buf[ix(c * HP + p, kx)];
             const cplx Zm = conj(buf[ix(c * HP + p, (kx == 0) ? 0 : L - kx)]);
-            cplx* q = dst + tx_off(c, kx, i0 + 2 * p, g);
+            cplx* q = dst + spec_off(c, kx, p);
             cplx v0 = 0.5 * (Zk + Zm), v1 = mul_mi(0.5 * (Zk - Zm));
-            if (acc) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
+            if (acc && SMO_X_SEQ_LATE_SUM) { v0 = v0 + ld_cplx<(SMO_X_NT & 4) != 0>(q); v1 = v1 + ld_cplx<(SMO_X_NT & 4) != 0>(q + 1); }
+            else if (acc) { v0 = v0 + old_sum[i][0]; v1 = v1 + old_sum[i][1]; }
             if ((SMO_X_NT & 8) && acc) {                           // the running sum comes back one whole step later
                 __builtin_nontemporal_store(d2_t{v0.re, v0.im}, reinterpret_cast<d2_t*>(q));
                 __builtin_nontemporal_store(d2_t{v1.re, v1.im}, reinterpret_cast<d2_t*>(q + 1));
@@ -709,6 +759,9 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 #ifndef SMO_X_SEQ_WAVES
 #define SMO_X_SEQ_WAVES SMO_X_WAVES
 #endif
+#ifndef SMO_X_SEQ_NT
+#define SMO_X_SEQ_NT SMO_X_FWD_NT      // threads of the sequential adjoint pass (experiments: 320, 384)
+#endif
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? SMO_X_SEQ_WAVES : SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
@@ -725,12 +778,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FU
         const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);
         tile = (size_t)q * (8 * PAIRED) + PAIRED * (r % 8) + r / 8;
     }
+    size_t i0 = tile * T;
+    if constexpr (T <= 8) {
+        if (g.tyl) {
+            // z-block-major Ty: walk the tiles y-fastest inside a z block (the 8/T tiles of a 128-byte line first, then y, then the block):
+            // consecutive workgroups then read consecutive lines of every kx block (a tile is independent of all others: any order is valid)
+            constexpr unsigned PER = 8 / T;
+            const size_t line = tile / PER, sub = tile - line * PER;
+            const size_t zb = line / g.G, y = line - zb * g.G;
+            i0 = y * g.Gzl + zb * 8 + sub * T;
+        }
+    }
     if constexpr (MODE == X_FUSED_ADJ_SEQ) {
-        if constexpr (HALF) x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
-        else x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, (const cplx*)tw_s, tile * T, tid);
+        if constexpr (HALF) x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid);
+        else x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, (const cplx*)tw_s, i0, tid);
     } else {
-        if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, tile * T, tid);
-        else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, tile * T, tid);
+        if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid);
+        else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, i0, tid);
     }
 }
 
@@ -852,6 +916,20 @@ public:
         return SMO_OK;
     }
     Geom geom(int nfields, int k = 0) const { Geom q = g; q.blk = (size_t)nfields * tzc; q.cblk = (size_t)cfg.world * 2 * tzc; q.zg0 = k * g.Gzl; return q; }
+    // Layout of Ty for the current chunk shape: z-block major (Geom::tyl, ty_off) when the local z planes come in whole blocks of 8 and the
+    // tuned kernels run; SMO_KD_TYL = 0 / 1 forces the plane / z-block layout (1 is ignored where it cannot apply), SMO_KD_YKX = 0 keeps the
+    // y pass's workgroups z-fastest.  fldc = elements of one field group of one chunk in whichever layout is larger.
+    int ty_layout_env = -1, ykx_env = -1;
+    void pick_ty_layout() {
+        const bool can = !any_size && g.Gzl % 8 == 0 && K <= TY_KMAX;
+        const bool want = ty_layout_env >= 0 ? ty_layout_env == 1 : g.G >= ty_layout_min_g;
+        g.tyl = (can && want) ? 1 : 0;
+        g.ykx = ykx_env >= 0 ? ykx_env : 1;      // (y_pass picks per direction)
+        g.tyk = (size_t)g.G * 8 + (ty_pad ? ty_pad : 8);
+        const size_t zb_elems = (size_t)(g.Gzl / 8) * g.tyk;          // per (component, kx): all its z blocks
+        fldc = (size_t)3 * g.a * (g.tyl ? std::max(g.typ, zb_elems) : g.typ);
+    }
+    int ty_layout_min_g = 0;                     // SMO_KD_TYL_MING: smallest grid that takes the z-block layout by default
     int set_chunks(int k) {
         const int Gzc = k > 0 ? g.Gzr / k : 0;
         // (one chunk of one slab may have any shape: odd G runs the run-time-length kernels, which pair its last line with zeros)
@@ -860,7 +938,8 @@ public:
             return SMO_ERR_ARG;
         }
         K = k; g.Gzl = Gzc; tzc = tzb / K; ngc = n_grid / K;
-        g.typ = (size_t)g.G * Gzc + (K <= TY_KMAX ? ty_pad : 0); fldc = (size_t)3 * g.a * g.typ;
+        g.typ = (size_t)g.G * Gzc + (K <= TY_KMAX ? ty_pad : 0);
+        pick_ty_layout();
         have_forward = false; zs_ready_fwd = zs_ready_adj = -1;
         return SMO_OK;
     }
@@ -900,10 +979,15 @@ public:
         { const char* e = getenv("SMO_KD_TYPAD"); ty_pad = e ? (size_t)atoi(e) : 8; }
         if (ty_pad % 8 != 0) { set_error("KDYN: SMO_KD_TYPAD must be a multiple of 8 elements (one 128-byte line)"); return SMO_ERR_ARG; }
         g.typ = (size_t)g.G * g.Gzl + ty_pad;
-        fld = (size_t)3 * g.a * ((size_t)g.G * g.Gzl + TY_KMAX * ty_pad);
+        { const char* e = getenv("SMO_KD_TYL"); if (e) ty_layout_env = atoi(e); }
+        { const char* e = getenv("SMO_KD_YKX"); if (e) ykx_env = atoi(e); }
+        { const char* e = getenv("SMO_KD_TYL_MING"); if (e) ty_layout_min_g = atoi(e); }
+        // one field group of Ty, all chunks: the planes with their padding, or the z blocks with theirs (G/8... Gzr/8 blocks of 8 G + pad per kx)
+        fld = (size_t)3 * g.a * ((size_t)g.G * g.Gzl + std::max((size_t)TY_KMAX * ty_pad, (size_t)(g.Gzl / 8 + 1) * std::max<size_t>(ty_pad, 8)));
         n_grid = (size_t)3 * g.G * g.G * g.Gzl;          // local slab of a grid vector: [3][G][G][Gzl]
         g.blk = tzb;
-        tzc = tzb; fldc = (size_t)3 * g.a * g.typ; ngc = n_grid;
+        tzc = tzb; ngc = n_grid;
+        pick_ty_layout();
         n_comp = 2;
         vec_len = n_grid;
         snapshot_doubles = 2 * 3 * nmode;
@@ -1038,7 +1122,7 @@ public:
         static constexpr int YZT = SMO_Y_ZT, YNT = 256;          // y pass: z columns per workgroup
         // forward x pass: (y,z) points per workgroup (12 / 6 FFTs; 128-B runs at G = 192).  256 threads: one middle-section item per thread
         // (HP * G/3 = 256), 102-105 VGPRs => 4 waves per SIMD = 16 per CU (192 threads: 148-154 VGPRs, 12 per CU): -5..-7 % on this kernel
-        static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
+        static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT, XSNT = SMO_X_SEQ_NT;
         static constexpr int XTA = 4 / H, XANT = SMO_X_ADJ_NT;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
@@ -1081,7 +1165,10 @@ public:
     }
     // y pass between field group `f` (of `nf`) of chunk `k` of the y-side exchange buffer and (that chunk of) one field group of Ty at `ty`
     int y_pass(bool inv, int f, int nf, cplx* ty, int k = 0) {
-        const Geom q = geom(nf, k);
+        Geom q = geom(nf, k);
+        // z-block-major Ty: the inverse pass (reads Tz, WRITES Ty) takes its workgroups kx-fastest — adjacent blocks of Ty are written together
+        // (256^3: 315 -> 289 us) —, the forward pass (reads Ty, writes Tz) z-fastest (265 vs 271 us kx-fastest); SMO_KD_YKX = 0 / 1 forces one order
+        q.ykx = ykx_env >= 0 ? ykx_env : (inv ? 1 : 0);
         if (!inv && ys == zs) zs_ready_fwd = zs_ready_adj = -1;      // one GPU: the y pass writes the buffer the z pass reads
         cplx* ex = ys + (size_t)k * q.cblk + (size_t)f * tzc;
         if (any_size) {
@@ -1142,7 +1229,7 @@ public:
                 default:
                     // adjoint: the field groups one after the other through the tile buffer (tiles as wide as the forward pass's), unless
                     // SMO_KD_ADJ_SEQ=0 asks for both at once in half-width tiles (round 1's kernel, kept for comparison)
-                    if (adj_seq) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    if (adj_seq) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XSNT, 8 / S::XT>), tiles(S::XT), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
                     else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q);
                     break;
             }
@@ -1416,6 +1503,12 @@ public:
         SMO_TRY(comm.set_transport(cfg.rank, cfg.world, a2a, ared, user));
         return attach_or_drop();
     }
+    int comm_set_peers(PeerGroup* grp, int rank) override {
+        if (cfg.world == 1 && !force_exchange) { set_error("comm_set_peers: single-slab context (nothing to exchange)"); return SMO_ERR_STATE; }
+        if (rank != cfg.rank || grp->world() != cfg.world) { set_error("comm_set_peers: rank %d of %d does not match the context (%d of %d)", rank, grp->world(), cfg.rank, cfg.world); return SMO_ERR_ARG; }
+        SMO_TRY(comm.set_peers(rank, grp));
+        return attach_or_drop();
+    }
     double comm_info(int key) const override {
         if (key == 0) return (double)K;
         if (key == 1) return 3.0 + (d_tystack ? 1.0 : 2.0);
@@ -1583,6 +1676,7 @@ public:
     double info(int key) const override {
         if (key == 0) return (double)ck;
         if (key == 2) return (double)graph_replays;
+        if (key == 3) return (double)g.tyl;
         return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 

@@ -156,12 +156,17 @@ public:
         return SMO_ERR_UNSUPPORTED;
     }
     virtual double comm_info(int key) const { (void)key; return 0.0; }
+    // ranks of ONE process (smo_create_multi): the context becomes rank `rank` of the group; collective like comm_init
+    virtual int comm_set_peers(class PeerGroup* g, int rank) { (void)g; (void)rank; set_error("multi-device contexts: KDYN only"); return SMO_ERR_UNSUPPORTED; }
     int set_stream(hipStream_t s);      // run on a caller-owned stream (e.g. torch's current stream) instead of the private one
 
-    // host-buffer variants: stage through context-owned device vectors
-    int forward_host(const double* const* X, double* J);
-    int adjoint_host(const double* const* X, int adjoint_type, double* const* grad);
-    int inner_host(const double* x, const double* y, double* out);
+    // host-buffer variants: stage through context-owned device vectors (a multi-device context scatters / gathers slabs instead)
+    virtual int forward_host(const double* const* X, double* J);
+    virtual int adjoint_host(const double* const* X, int adjoint_type, double* const* grad);
+    virtual int inner_host(const double* x, const double* y, double* out);
+    // the kernel timing behind smo_timing_* (a multi-device context answers with rank 0's) and a wait for everything enqueued
+    virtual Timing& tm() { return timing; }
+    virtual int sync_all() { SMO_HIP(hipSetDevice(cfg.device)); SMO_HIP(hipStreamSynchronize(stream)); return SMO_OK; }
 
 protected:
     int base_init();             // device selection, stream, staging buffers (needs n_comp / vec_len set)
@@ -173,5 +178,7 @@ Context* make_sh23(const smo_config& cfg);
 Context* make_shb23(const smo_config& cfg);
 Context* make_kdyn(const smo_config& cfg);
 Context* make_pois(const smo_config& cfg);
+// one context that slab-decomposes a KDYN problem over several GPUs of this process (csrc/multi.cpp)
+Context* make_multi(const smo_config& cfg, int ndev, const int* dev_ids);
 
 }  // namespace smo

@@ -36,10 +36,13 @@ class SnapshotStack:
 
 
 class KDynDomain:
-    def __init__(self, Npts, X=(0., 2. * np.pi), device=0, ckpt=1):
+    def __init__(self, Npts, X=(0., 2. * np.pi), device=0, ckpt=1, devices=None):
         """ckpt: keep every ckpt-th snapshot and recompute the rest during the adjoint (1 = keep all like the reference,
-        0 = smallest interval whose stack fits the free HBM)."""
+        0 = smallest interval whose stack fits the free HBM).
+        devices: a list of GPU ordinals — this ONE process then runs the problem slab-decomposed over them (smo_create_multi: no launcher,
+        no RCCL; the callbacks keep taking and returning the reference's full vectors)."""
         self.Npts, self.interval, self.device, self.ckpt = int(Npts), (float(X[0]), float(X[1])), device, ckpt
+        self.devices = [int(d) for d in devices] if devices is not None and len(devices) > 1 else None
         self.G = 3 * self.Npts // 2
         self.kmax = (self.Npts - 1) // 2
         self.a, self.m = self.kmax + 1, 2 * self.kmax + 1
@@ -50,8 +53,11 @@ class KDynDomain:
     def context(self, Rm, dt, N_ITERS, Cost_function="Final"):
         key = (float(Rm), float(dt), int(N_ITERS), Cost_function)
         if key not in self._ctx:
-            self._ctx[key] = _capi.Context(_capi.SMO_KDYN, self.Npts, self.interval, dt, N_ITERS, Rm, cost=Cost_function,
-                                           device=self.device, ckpt=self.ckpt)
+            if self.devices:
+                self._ctx[key] = _capi.MultiContext(self.Npts, self.interval, dt, N_ITERS, Rm, self.devices, cost=Cost_function, ckpt=self.ckpt)
+            else:
+                self._ctx[key] = _capi.Context(_capi.SMO_KDYN, self.Npts, self.interval, dt, N_ITERS, Rm, cost=Cost_function,
+                                               device=self.device, ckpt=self.ckpt)
         return self._ctx[key]
 
     def drop_contexts(self):

@@ -81,7 +81,7 @@ def test_gpus_flag_starts_the_ranks_itself():
     c = d["config"]
     for k in ("compute_ms_per_step_pair", "exchange_ms_per_step_pair", "exchange_calls_per_step_pair", "wall_ms_per_step_pair", "rccl_library"):
         assert k in c, k
-    assert c["compute_ms_per_step_pair"] > 0 and c["exchange_ms_per_step_pair"] > 0 and abs(c["exchange_calls_per_step_pair"] - 4.0) < 0.2
+    assert c["compute_ms_per_step_pair"] > 0 and c["exchange_ms_per_step_pair"] > 0 and 4.0 <= c["exchange_calls_per_step_pair"] <= 4.5      # 4 per step pair + the transforms of X and of the gradients (20 steps here)
     assert c["wall_ms_per_step_pair"] >= 0.5 * c["compute_ms_per_step_pair"]
     assert c["rccl_library"] is None                                 # callback transport: no RCCL communicator, none claimed
 

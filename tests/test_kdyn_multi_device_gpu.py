@@ -1,0 +1,103 @@
+"""smo_create_multi: ONE process, ONE context, the 3-D problem slab-decomposed over several devices (include/smo.h).
+
+A one-GPU box lists its device several times (dev_ids = [0, 0], [0, 0, 0, 0]): every rank is then a worker thread with its own streams and
+buffers on that GPU and every transpose goes through the PeerGroup protocol (events, host barriers, pulls from the peers' buffers) — the
+only thing a one-GPU box cannot exercise is that the pulled bytes cross xGMI.  Results are compared with the oracle and, bit for bit where
+the arithmetic is the same, with the single-device context."""
+import numpy as np
+import pytest
+
+from spheremanopt_amd import _capi, kdyn
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("N,devs,cost,adj", [(16, [0, 0], "Final", "Discrete"), (16, [0, 0, 0, 0], "Integrated", "Discrete"),
+                                             (24, [0, 0], "Final", "Continuous"), (32, [0, 0, 0, 0], "Integrated", "Continuous")])
+def test_multi_device_context_vs_oracle(N, devs, cost, adj):
+    from oracle.kdyn import KDynOracle
+    n, dt = 6, 5e-3
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), dt, n, 1.0, devs, cost=cost)
+    assert ctx.vec_len == 3 * G ** 3 and ctx.ncomp == 2            # the caller's vectors are the reference's full ones
+    J = ctx.forward([B, U])
+    gB, gU = ctx.adjoint(None, adj)
+    o = KDynOracle(N, Rm=1.0, dt=dt, N_ITERS=n, Cost_function=cost)
+    Jo = o.forward([B, U]); goB, goU = o.adjoint([B, U], Adjoint_type=adj)
+    assert abs(J - Jo) <= RTOL * abs(Jo), (J, Jo)
+    assert rel(gB, goB) < RTOL and rel(gU, goU) < RTOL, (rel(gB, goB), rel(gU, goU))
+    ip = ctx.inner(B, gB)
+    assert abs(ip - o.inner(B, goB)) <= RTOL * abs(o.inner(B, goB))
+    ctx.close()
+
+
+def test_multi_device_context_equals_single_device_and_repeats():
+    """Same kernels, same per-mode arithmetic: J agrees with the one-device context to the rounding of the energy reduction (the
+    partial sums are split differently), gradients to 1e-12; a second evaluation on the same context is bit-identical to the first."""
+    N, n, dt = 32, 10, 2e-3
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 3), kdyn.synthetic_field(G, 4)
+    one = _capi.Context(_capi.SMO_KDYN, N, (0., 2. * np.pi), dt, n, 1.0)
+    J1 = one.forward([B, U]); g1 = one.adjoint(None)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), dt, n, 1.0, [0, 0, 0, 0])
+    J4 = ctx.forward([B, U]); g4 = [g.copy() for g in ctx.adjoint(None)]
+    assert abs(J4 - J1) <= 1e-13 * abs(J1)
+    assert rel(g4[0], g1[0]) < 1e-12 and rel(g4[1], g1[1]) < 1e-12
+    J4b = ctx.forward([B, U]); g4b = ctx.adjoint(None)
+    assert J4b == J4 and np.array_equal(g4b[0], g4[0]) and np.array_equal(g4b[1], g4[1])
+    one.close(); ctx.close()
+
+
+def test_multi_device_context_with_checkpoint_windows():
+    N, n, dt = 24, 9, 5e-3
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    ref = _capi.MultiContext(N, (0., 2. * np.pi), dt, n, 1.0, [0, 0])
+    Jr = ref.forward([B, U]); gr = [g.copy() for g in ref.adjoint(None)]
+    ref.close()
+    ck = _capi.MultiContext(N, (0., 2. * np.pi), dt, n, 1.0, [0, 0], ckpt=3)
+    assert ck.get(0) == 3
+    Jc = ck.forward([B, U]); gc = ck.adjoint(None)
+    assert Jc == Jr and np.array_equal(gc[0], gr[0]) and np.array_equal(gc[1], gr[1])       # recomputed states are the same states
+    ck.close()
+
+
+def test_reference_callbacks_on_a_multi_device_domain():
+    """The drop-in surface: the reference's callbacks + optimiser in ONE process over a slab-decomposed context, no launcher."""
+    from spheremanopt_amd.sphere_opt import Optimise_On_Multi_Sphere
+    N, n, dt = 16, 8, 5e-3
+    res = []
+    for devices in (None, [0, 0]):
+        dom = kdyn.KDynDomain(N, devices=devices)
+        G = dom.G
+        B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+        buf = kdyn.GEN_BUFFER(N, dom, n)
+        args_f = [dom, 1.0, dt, n, n, buf, "Final", "Discrete"]
+        R, F, X = Optimise_On_Multi_Sphere([B, U], [1.0, 1.0], kdyn.FWD_Solve_IVP_Lin, kdyn.ADJ_Solve_IVP_Lin, kdyn.Inner_Prod_3,
+                                            args_f=args_f, args_IP=(dom, None), max_iters=3, alpha_k=1., LS='LS_wolfe', CG=True, verbose=False)
+        res.append((F, X))
+        dom.drop_contexts()
+    (F1, X1), (F2, X2) = res
+    assert len(F1) == len(F2) and np.allclose(F1, F2, rtol=1e-9, atol=0)
+    assert rel(X2[0], X1[0]) < 1e-8 and rel(X2[1], X1[1]) < 1e-8
+
+
+def test_errors():
+    with pytest.raises(_capi.SmoError):
+        _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 4, 1.0, [0, 0, 0])           # 3 devices do not divide a = 8
+    with pytest.raises(_capi.SmoError):
+        _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 4, 1.0, [0, 99])             # no such device
+    ctx = _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 4, 1.0, [0, 0])
+    with pytest.raises(_capi.SmoError):
+        ctx.adjoint(None)                                                        # the hidden contract: adjoint needs a forward solve
+    with pytest.raises(ValueError):
+        ctx.forward([np.zeros(5), np.zeros(5)])
+    with pytest.raises(_capi.SmoError):
+        ctx.snapshot(0)
+    ctx.close()

@@ -7,7 +7,7 @@ N=${2:-128}; IT=${3:-200}
 mkdir -p gpurun_out
 for v in $1; do
   if [ "$v" = base ]; then unset SMO_LIB; else export SMO_LIB=$PWD/xp_tmp/lib/libsmo_$v.so; fi
-  timeout -k 10 300 python bench.py --npts $N --iters $IT --steps 2 --warmup 1 --no-secondary --no-cpu-baseline > gpurun_out/v_$v.json 2> gpurun_out/v_$v.err || { echo "variant $v failed"; tail -3 gpurun_out/v_$v.err; exit 1; }
+  timeout -k 10 300 python bench.py --npts $N --iters $IT --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-host-vectors > gpurun_out/v_$v.json 2> gpurun_out/v_$v.err || { echo "variant $v failed"; tail -3 gpurun_out/v_$v.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open('gpurun_out/v_$v.json').read().strip().splitlines()[-1])
