@@ -195,6 +195,8 @@ typedef int (*smo_allreduce_fn)(void* user, double* host_values, int n);      /*
 int smo_comm_unique_id(void* id128);
 int smo_comm_init(smo_ctx* ctx, const void* id128);
 int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn all_to_all, smo_allreduce_fn all_reduce_sum, void* user);
+/* (all three arguments NULL: the null transport — exchanges and reductions do nothing.  For profiling one rank's share of a W-way decomposition
+ * on a single GPU through the real in-library loop, tools/prof_slab_geometry.py; the results of such a solve are meaningless.) */
 /* key 0: pipelined z chunks per exchange; 1: field-group exchanges per forward+adjoint step pair; 2: 1 if the transport is RCCL */
 int smo_comm_get(const smo_ctx* ctx, int key, double* value);
 /* File of the librccl this library bound for smo_comm_unique_id / smo_comm_init (dladdr of its ncclGetUniqueId), "" if none can be

@@ -103,6 +103,11 @@ int SlabComm::init_rccl(int r, int w, const void* unique_id) {
 }
 
 int SlabComm::set_transport(int r, int w, smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user) {
+    if (!a2a && !ared && !user) {                          // the null transport: nothing moves (profiling one rank's share on one GPU)
+        if (ready()) { set_error("smo_comm_set_transport: the context already has a communicator"); return SMO_ERR_STATE; }
+        null_ = true; rank = r; world = w;
+        return SMO_OK;
+    }
     if (!a2a || !ared) { set_error("smo_comm_set_transport: null function"); return SMO_ERR_ARG; }
     if (ready()) { set_error("smo_comm_set_transport: the context already has a communicator"); return SMO_ERR_STATE; }
     a2a_ = a2a; ared_ = ared; user_ = user; rank = r; world = w;
@@ -111,7 +116,7 @@ int SlabComm::set_transport(int r, int w, smo_alltoall_fn a2a, smo_allreduce_fn 
 
 void SlabComm::reset() {
     if (nccl_ && g_rccl.handle) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(nccl_));
-    nccl_ = nullptr; a2a_ = nullptr; ared_ = nullptr; user_ = nullptr; peers_ = nullptr;
+    nccl_ = nullptr; a2a_ = nullptr; ared_ = nullptr; user_ = nullptr; peers_ = nullptr; null_ = false;
 }
 
 int SlabComm::set_peers(int r, PeerGroup* g) {
@@ -207,6 +212,7 @@ const char* SlabComm::library_path() {
 
 int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s) {
     if (peers_) return peers_->alltoall(rank, src, dst, bytes_per_peer, s);
+    if (null_) return SMO_OK;
     if (nccl_) {
         ncclComm_t c = static_cast<ncclComm_t>(nccl_);
         const size_t cnt = bytes_per_peer / sizeof(double);
@@ -229,6 +235,11 @@ int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStr
 
 int SlabComm::allreduce_sum(double* vals, int n, hipStream_t s, double* dev_scratch) {
     if (peers_) return peers_->allreduce_sum(rank, vals, n, s);
+    if (null_) {                                           // as if every rank had contributed what this one did
+        SMO_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) vals[i] *= world;
+        return SMO_OK;
+    }
     if (nccl_) {
         ncclComm_t c = static_cast<ncclComm_t>(nccl_);
         SMO_HIP(hipMemcpyAsync(dev_scratch, vals, n * sizeof(double), hipMemcpyHostToDevice, s));

@@ -56,7 +56,7 @@ class SlabComm {
 public:
     int rank = 0, world = 1;
     ~SlabComm();
-    bool ready() const { return nccl_ != nullptr || a2a_ != nullptr || peers_ != nullptr; }
+    bool ready() const { return nccl_ != nullptr || a2a_ != nullptr || peers_ != nullptr || null_; }
     int set_peers(int rank, PeerGroup* g);
     bool is_rccl() const { return nccl_ != nullptr; }
     int init_rccl(int rank, int world, const void* unique_id);
@@ -77,6 +77,7 @@ private:
     smo_allreduce_fn ared_ = nullptr;
     void* user_ = nullptr;
     PeerGroup* peers_ = nullptr;     // not owned
+    bool null_ = false;              // the null transport (set_transport with three null arguments): exchanges and reductions do nothing
 };
 
 }  // namespace smo

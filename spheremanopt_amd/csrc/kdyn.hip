@@ -1471,9 +1471,12 @@ public:
         }
         int k = 0;
         if (const char* e = getenv("SMO_SLAB_CHUNKS")) k = atoi(e);
-        // default: up to 4 chunks of at least 9216 (y,z) points — below that the grid-side kernels are launch-bound and chunking
-        // costs more than it hides (profiles/r01_rccl_one_rank.jsonl)
-        if (k <= 0) k = cfg.world > 1 ? std::max(1, std::min(4, (int)(((size_t)g.G * g.Gzr) / 9216))) : 1;
+        // default: up to 4 chunks of at least 36864 (y,z) points (one 192 x 192 plane set).  Chunking is not free: with the null transport
+        // (no exchange at all) the 256^3 step pair of an 8-way decomposition takes 570 us with one chunk and 739 us with two, 1075 / 1390 us
+        // 4-way with 1 / 4 (profiles/r03_slab_geometry_256.jsonl) — smaller kernels fill the GPU worse (a fused x pass of 9216 points is
+        // 1152 tiles for 1024 slots) and every chunk adds event traffic — so it only pays where the transposes are slow enough to be worth
+        // hiding, which a one-GPU measurement cannot tell: LibSlabKDyn.autotune_chunks / SMO_SLAB_CHUNKS decide on the node itself.
+        if (k <= 0) k = cfg.world > 1 ? std::max(1, std::min(4, (int)(((size_t)g.G * g.Gzr) / 36864))) : 1;
         while (k > 1 && (g.Gzr % k || (g.Gzr / k) % 2 || ((size_t)g.G * (g.Gzr / k)) % 4)) --k;
         if (k != K) SMO_TRY(set_chunks(k));
         SMO_TRY(pipeline_resources());

@@ -33,4 +33,15 @@ def test_documented_ctypes_stub_runs():
     g2 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
     assert np.array_equal(g[0], g2[0]) and np.array_equal(g[1], g2[1])
     assert ip == kdyn.Inner_Prod_3(B, g2[0], dom)
+    # section 2c: the same stub on a multi-device context (ONE process, the box's GPU listed twice), as documented
+    multi = [b for b in blocks if "smo_create_multi" in b]
+    assert len(multi) == 1
+    mcode = multi[0].replace("smo_config(3, 128, 0.0, 2*np.pi, 1e-3, 1000,", "smo_config(3, 16, 0.0, 2*np.pi, 1e-3, 5,")
+    assert "smo_config(3, 16," in mcode
+    exec(compile(mcode, "INTEGRATION.md#2c", "exec"), ns)
+    Jm = ns["FWD_Solve_IVP_Lin_multi"]([B, U])
+    gm = ns["ADJ_Solve_IVP_Lin_multi"]([B, U])
+    assert abs(Jm - J) <= 1e-13 * abs(J)
+    assert np.linalg.norm(gm[0] - g[0]) <= 1e-12 * np.linalg.norm(g[0]) and np.linalg.norm(gm[1] - g[1]) <= 1e-12 * np.linalg.norm(g[1])
+    ns["L"].smo_destroy(ns["mctx"])
     ns["L"].smo_destroy(ns["ctx"])
