@@ -141,7 +141,11 @@ int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double
  *   - buffers come from a per-device pool (smo_vec_free returns them to it; smo_vec_pool_release gives the memory back);
  *   - smo_vec_axpby: out[i] = fl( fl(a*x[i]) + fl(b*y[i]) ), y == NULL: out[i] = fl(a*x[i]); products and sum are rounded
  *     separately (no fused multiply-add), i.e. bit for bit what NumPy computes for a*x + b*y; out may alias x or y;
- *   - all of them are synchronous. */
+ *   - all of them are synchronous — and they run on a stream of the pool's own: the operands must be COMPLETE when the call is made
+ *     (results of smo_*_dev calls are: those return after their stream has drained; work a caller has enqueued itself on another
+ *     stream, e.g. the one handed to smo_set_stream, must be synchronised first);
+ *   - smo_vec_axpby takes any 8-byte-aligned device pointers (pool buffers are 256-byte aligned and use 16-byte accesses; a view at an
+ *     odd element offset of a caller's own buffer runs the same arithmetic one element per lane); anything else: SMO_ERR_ARG. */
 int smo_vec_alloc(int device, size_t n, double** out_dev);
 int smo_vec_free(int device, double* dev);
 int smo_vec_pool_release(int device);

@@ -1122,7 +1122,11 @@ public:
         static constexpr int YZT = SMO_Y_ZT, YNT = 256;          // y pass: z columns per workgroup
         // forward x pass: (y,z) points per workgroup (12 / 6 FFTs; 128-B runs at G = 192).  256 threads: one middle-section item per thread
         // (HP * G/3 = 256), 102-105 VGPRs => 4 waves per SIMD = 16 per CU (192 threads: 148-154 VGPRs, 12 per CU): -5..-7 % on this kernel
-        static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT, XSNT = SMO_X_SEQ_NT;
+        static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
+        // sequential adjoint pass: one middle-section item (j, line pair) per thread — it keeps 9 complex grid values of omega per item in
+        // registers, a second item per thread spills (G = 480: 320 items, 168 VGPRs + 241 spilled with 256 threads; 320 threads: none)
+        static constexpr int XITEMS = (XT / 2) * (L / 3);
+        static constexpr int XSNT = XITEMS > SMO_X_SEQ_NT ? ((XITEMS + 63) / 64) * 64 : SMO_X_SEQ_NT;
         static constexpr int XTA = 4 / H, XANT = SMO_X_ADJ_NT;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };

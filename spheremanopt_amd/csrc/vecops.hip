@@ -7,6 +7,7 @@
 // serialise the device each time) and ONE arithmetic kernel,  out = a*x + b*y,  whose two products and one sum are rounded
 // separately exactly as NumPy evaluates  a*x + b*y  (no fused multiply-add), so that the iterate sequence of an optimisation
 // run on device vectors is bit-identical to the one on NumPy vectors.
+#include <cstdint>
 #include <map>
 #include <mutex>
 
@@ -34,25 +35,42 @@ int pool_for(int device, DevicePool** out) {
     return SMO_OK;
 }
 
-// out = fl(fl(a*x) + fl(b*y)); HAS_Y = false: out = fl(a*x).  __dmul_rn / __dadd_rn are never contracted into an fma.
+// out = fl(fl(a*x) + fl(b*y)); HAS_Y = false: out = fl(a*x).  The products and the sum must NOT be contracted into an fma: HIP's __dmul_rn /
+// __dadd_rn are plain * and + to the compiler, which (with hipcc's default -ffp-contract=fast) fused fl(a*x) + b*y into v_fmac_f64 — one
+// rounding less than NumPy whenever neither factor is +-1 (found in round 3 by calling smo_vec_axpby directly; the optimiser's operators
+// always have a factor +-1 or no second operand and were never affected).  `#pragma clang fp contract(off)` pins the two-rounding form; the
+// ISA is checked in tests/test_no_device_calls.py.
 template <bool HAS_Y>
 __global__ __launch_bounds__(256) void vec_axpby(size_t n2, size_t n, double a, const double* x, double b, const double* y, double* out) {
+#pragma clang fp contract(off)
     const double2* x2 = reinterpret_cast<const double2*>(x);
     const double2* y2 = reinterpret_cast<const double2*>(y);
     double2* o2 = reinterpret_cast<double2*>(out);
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
         double2 u = x2[i], r;
-        r.x = __dmul_rn(a, u.x); r.y = __dmul_rn(a, u.y);
+        r.x = a * u.x; r.y = a * u.y;                       // (plain operators: the header's __dmul_rn carries its own `contract` flag when inlined)
         if (HAS_Y) {
             double2 v = y2[i];
-            r.x = __dadd_rn(r.x, __dmul_rn(b, v.x)); r.y = __dadd_rn(r.y, __dmul_rn(b, v.y));
+            const double px = b * v.x, py = b * v.y;
+            r.x = r.x + px; r.y = r.y + py;
         }
         o2[i] = r;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
-        double r = __dmul_rn(a, x[n - 1]);
-        if (HAS_Y) r = __dadd_rn(r, __dmul_rn(b, y[n - 1]));
+        double r = a * x[n - 1];
+        if (HAS_Y) { const double q = b * y[n - 1]; r = r + q; }
         out[n - 1] = r;
+    }
+}
+
+// the same arithmetic one element per lane: vectors that are only 8-byte aligned (a view at an odd element offset of a caller's buffer)
+template <bool HAS_Y>
+__global__ __launch_bounds__(256) void vec_axpby_scalar(size_t n, double a, const double* x, double b, const double* y, double* out) {
+#pragma clang fp contract(off)
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double r = a * x[i];
+        if (HAS_Y) { const double q = b * y[i]; r = r + q; }
+        out[i] = r;
     }
 }
 
@@ -144,6 +162,21 @@ int smo_vec_axpby(int device, size_t n, double a, const double* x, double b, con
     if (!x || !out || n == 0) { set_error("smo_vec_axpby: bad argument"); return SMO_ERR_ARG; }
     DevicePool* p = nullptr;
     { std::lock_guard<std::mutex> lk(g_mu); SMO_TRY(pool_for(device, &p)); }
+    // the kernel reads / writes 16 bytes per lane: pool buffers are 256-byte aligned, a view into a caller's own buffer at an odd element
+    // offset is not — such vectors take the one-element-per-lane kernel (same rounding)
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | (y ? reinterpret_cast<uintptr_t>(y) : 0)) & 15u) == 0;
+    if (!aligned) {
+        if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | (y ? reinterpret_cast<uintptr_t>(y) : 0)) & 7u) {
+            set_error("smo_vec_axpby: vectors must be 8-byte aligned (x=%p y=%p out=%p)", (const void*)x, (const void*)y, (void*)out);
+            return SMO_ERR_ARG;
+        }
+        const unsigned nwg1 = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+        if (y) hipLaunchKernelGGL((vec_axpby_scalar<true>), dim3(nwg1), dim3(256), 0, p->stream, n, a, x, b, y, out);
+        else hipLaunchKernelGGL((vec_axpby_scalar<false>), dim3(nwg1), dim3(256), 0, p->stream, n, a, x, b, y, out);
+        SMO_HIP(hipGetLastError());
+        SMO_HIP(hipStreamSynchronize(p->stream));
+        return SMO_OK;
+    }
     const size_t n2 = n / 2;
     const unsigned nwg = (unsigned)std::min<size_t>(4096, (n2 + 255) / 256 + 1);
     if (y) hipLaunchKernelGGL((vec_axpby<true>), dim3(nwg), dim3(256), 0, p->stream, n2, n, a, x, b, y, out);

@@ -483,6 +483,7 @@ def Optimise_On_Multi_Sphere(X_0, M_0, f, myfprime, inner_prod, args_f=(), args_
         for c, radius in enumerate(M_0):
             if alpha_k is None:
                 print("\n Couldn't find a descent direction .... Terminating \n")
+                log.close()
                 return R.Residual, R.Function_Value, R.X_opt
             X_k[c] = Update_vector(X_k[c], alpha_k, d_k[c], radius, inner_prod, args_IP, kwargs_IP)
             error[c] = inner_prod(g_k[c], g_k[c], *args_IP, **kwargs_IP) ** 0.5

@@ -36,6 +36,33 @@ def test_algebra_rounds_like_numpy(n):
         X + DeviceVector.from_numpy(np.zeros(n + 1))
 
 
+def test_axpby_on_views_that_are_only_8_byte_aligned():
+    """smo_vec_axpby on a view at an odd element offset of a caller's buffer: same rounding through the one-element-per-lane
+    kernel; a pointer that is not even 8-byte aligned is refused; and the device entry points refuse vectors of the wrong length / device."""
+    import ctypes as C
+    n = 1001
+    rs = np.random.RandomState(5)
+    x, y = rs.standard_normal(n + 1), rs.standard_normal(n + 1)
+    X, Y, O = DeviceVector.from_numpy(x), DeviceVector.from_numpy(y), DeviceVector(n + 1)
+    a, b = 1.25, -0.3333333333333333
+    L = _capi.lib()
+    _capi._check(L.smo_vec_axpby(0, n, a, C.c_void_p(X.ptr + 8), b, C.c_void_p(Y.ptr + 8), C.c_void_p(O.ptr + 8)))
+    assert np.array_equal(O.numpy()[1:], a * x[1:] + b * y[1:])
+    _capi._check(L.smo_vec_axpby(0, n, a, C.c_void_p(X.ptr + 8), b, None, C.c_void_p(O.ptr)))          # mixed alignment, no y
+    assert np.array_equal(O.numpy()[:n], a * x[1:])
+    assert L.smo_vec_axpby(0, n, a, C.c_void_p(X.ptr + 4), b, None, C.c_void_p(O.ptr)) == 1 and b"8-byte aligned" in L.smo_last_error()
+    dom = kdyn.KDynDomain(8)
+    ctx = dom.context(1.0, 1e-3, 2)
+    good = [DeviceVector(ctx.vec_len), DeviceVector(ctx.vec_len)]
+    with pytest.raises(ValueError):
+        ctx.forward_dev([DeviceVector(ctx.vec_len - 1), good[1]])
+    with pytest.raises(ValueError):
+        ctx.forward_dev([good[0]])
+    with pytest.raises(ValueError):
+        ctx.inner_dev(good[0], DeviceVector(5))
+    dom.drop_contexts()
+
+
 def test_pool_recycles_and_releases():
     release_pool(0)
     live0, _ = pool_bytes(0)

@@ -45,18 +45,52 @@ def test_sh23_and_shb23_scripts(in_tmp_cwd):
 
 
 def test_poiseuille_script(in_tmp_cwd):
-    """FWD_Solve_Poiseuille.py's __main__ (Discrete formulation) at a reduced resolution: Taylor test with the kinetic-energy cost, then
-    a few CG/Wolfe iterations with the mix-norm cost (the reference's default, s = 1); the cost must not increase."""
+    """FWD_Solve_Poiseuille.py's __main__ at a reduced resolution: Taylor test with the kinetic-energy cost, then a few CG/Wolfe iterations with
+    the mix-norm cost (the reference's default, s = 1), Discrete formulation; then the script's default "Continuous" formulation.  The cost must
+    never increase.  Line-search warnings are attributed run by run: the Discrete formulation has the exact gradient of its cost (Taylor
+    exponent 2) and must not produce any; the Continuous one differentiates the continuous problem — its gradient is only O(dt)-consistent
+    with the discrete cost (as in the reference, FWD_Solve_Poiseuille.py:1161-1318), so a Wolfe search near the optimum may give up: that is
+    the one run allowed to warn, and only with the optimiser's own LineSearchWarning."""
+    import warnings
     from spheremanopt_amd.examples import poiseuille_optimise
-    R, F, X, AA = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.1", "--s", "0", "--max-iters", "3", "--test-gradient", "--quiet"])
+    from spheremanopt_amd.sphere_opt import LineSearchWarning
+
+    def run(args):
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            out = poiseuille_optimise.main(args)
+        return out, rec
+
+    (R, F, X, AA), w_taylor = run(["--nx", "32", "--nz", "24", "--T", "0.1", "--s", "0", "--max-iters", "3", "--test-gradient", "--quiet"])
     assert np.all(np.abs(AA[4, :4] - 2.0) < 2e-2), AA
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
-    R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "1", "--max-iters", "3", "--quiet"])
+    (R, F, X, _), w_mix = run(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "1", "--max-iters", "3", "--quiet"])
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1))
     assert len(X) == 1 and X[0].shape == (2 * 48 * 36,)
     # the script's default formulation ("Continuous"): same grid, 32 x 24 modes; the cost must not increase either
-    R, F, X, _ = poiseuille_optimise.main(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "0", "--max-iters", "3", "--continuous", "--quiet"])
+    (R, F, X, _), w_cnts = run(["--nx", "32", "--nz", "24", "--T", "0.25", "--s", "0", "--max-iters", "3", "--continuous", "--quiet"])
     assert len(F) >= 1 and all(F[i + 1] >= F[i] for i in range(len(F) - 1)) and X[0].shape == (2 * 48 * 36,)
+    names = {"Discrete s=0 (+Taylor test)": w_taylor, "Discrete s=1": w_mix, "Continuous s=0": w_cnts}
+    ls = {k: [str(w.message) for w in v if issubclass(w.category, LineSearchWarning)] for k, v in names.items()}
+    # Which run warns, and why (measured, round 3): the kinetic-energy runs — Discrete AND Continuous — are silent.  The mix-norm run (s = 1)
+    # warns twice, "could not find a solution less than or equal to amax: 100.0" + "did not converge", and the optimiser then stops with
+    # "Couldn't find a descent direction" exactly like the reference's (Sphere_Grad_Descent.py:436, 477, 791-793): over T = 0.25 the mix-norm
+    # hardly moves, phi keeps decreasing all the way to the step cap alpha_max = alpha_k = 100 the script passes (FWD_Solve_Poiseuille.py:1777)
+    # and scalar_search_wolfe2 gives up at the cap.  It is the reference's line search meeting its own cap, not a gradient defect: the mix-norm
+    # gradient of exactly this configuration is checked against a central difference below.
+    assert not ls["Discrete s=0 (+Taylor test)"] and not ls["Continuous s=0"], ls
+    assert all("amax" in m or "did not converge" in m for m in ls["Discrete s=1"]), ls
+    from spheremanopt_amd import poiseuille as pz
+    dom, U0 = pz.Generate_IC(48, 36, E_0=0.02, seed=42)
+    _, dU0 = pz.Generate_IC(48, 36, E_0=0.02, seed=7)
+    buf = pz.GEN_BUFFER(48, 36, dom, 50)
+    args_f = [dom, 500., 0.05, 50, buf, 5e-3, 1, 1., 0.125]
+    J0 = pz.FWD_Solve(U0, *args_f); g = pz.ADJ_Solve(U0, *args_f)
+    d = pz.Inner_Prod(g[0], dU0[0], dom)
+    h = 1e-2
+    fd = (pz.FWD_Solve([U0[0] + h * dU0[0]], *args_f) - pz.FWD_Solve([U0[0] - h * dU0[0]], *args_f)) / (2 * h)
+    assert abs(d - fd) <= 2e-3 * abs(fd), (d, fd, J0)
+    dom.drop_contexts()
 
 
 def test_on_disk_products(in_tmp_cwd):

@@ -315,6 +315,26 @@ def test_communicator_errors():
     with pytest.raises(_capi.SmoError) as e:
         ctx.forward([x, x])
     assert "transport failed" in str(e.value) and isinstance(ctx._transport_error, RuntimeError)
+    # ranks that cannot agree (here: the "other rank" reports checkpoint interval 2 against this rank's 1): smo_comm_set_transport fails AND
+    # drops the transport again — the context is back in its "no communicator" state instead of keeping a live one whose next solve would
+    # hang in a mismatched all-to-all — and the call can be repeated once the ranks agree
+    c2 = _capi.Context(_capi.SMO_KDYN, 16, (0., 2 * np.pi), 1e-3, 2, 1.0, rank=0, world=2)
+    def ok_a2a(src, dst, nbytes, stream):
+        pass
+    def disagree(vals, n):
+        if n == 4:
+            vals[0] += vals[0]; vals[1] += 2.0; vals[2] += 4.0; vals[3] += vals[3]
+        else:
+            for i in range(n):
+                vals[i] = 2.0 * vals[i]
+    with pytest.raises(_capi.SmoError) as e:
+        c2.comm_set_transport(ok_a2a, disagree)
+    assert e.value.code == 4 and "different checkpoint intervals" in str(e.value) and "dropped" in str(e.value)
+    with pytest.raises(_capi.SmoError) as e:
+        c2.forward([x, x])
+    assert e.value.code == 4 and "no communicator" in str(e.value)
+    c2.comm_set_transport(ok_a2a, ared)                      # second attempt, the ranks agree now
+    assert np.isfinite(c2.forward([x, x]))
 
 
 def _autotune_worker(rank, world, port, N, n, out):

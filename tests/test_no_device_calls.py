@@ -73,3 +73,24 @@ def test_the_scanner_flags_the_round2_failure(tmp_path):
     flagged = {h[0] for h in res["ipra"][2]}
     assert any("shb_forward_kernelILi0E" in k for k in flagged) and any("shb_adjoint_cnts_kernelILi0E" in k for k in flagged), flagged
     assert not res["no_ipra"][2]
+
+
+@needs_llvm
+def test_axpby_kernels_are_not_contracted_into_fma():
+    """smo_vec_axpby promises NumPy's rounding, fl(fl(a*x) + fl(b*y)) (include/smo.h).  hipcc's default -ffp-contract=fast had turned the
+    sum into v_fmac_f64 (one rounding less whenever neither factor is +-1); the kernels now pin the two-rounding form and this test keeps
+    the ISA honest: no fused multiply-add in any vec_axpby kernel of the shipped library."""
+    import tempfile
+    found = 0
+    with tempfile.TemporaryDirectory() as w:
+        for co in scan.code_objects(_capi.LIB_PATH, w):
+            dis = subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True, check=True).stdout
+            cur = None
+            for ln in dis.splitlines():
+                m = re.match(r"^[0-9a-f]{16} <(\S+)>:", ln)
+                if m:
+                    cur = m.group(1)
+                    found += "vec_axpby" in cur
+                elif cur and "vec_axpby" in cur:
+                    assert not re.search(r"\bv_(pk_)?fma?c?_f64\b|\bv_fma_f64\b|\bv_fmac_f64", ln), (cur, ln.strip())
+    assert found >= 4                                            # <true>/<false> of the 16-byte and the 8-byte kernel

@@ -16,7 +16,7 @@ import subprocess
 for k, v in rows.items():
     name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"\(.*", "", name.replace("void smo::(anonymous namespace)::", ""))
-    if not re.search(r"<(192|384),", name):
+    if not re.search(r"<(%s)," % (__import__("os").environ.get("SMO_RES_G", "192|384")), name):
         continue
     print("%-44s VGPR %3d  spill %d  scratch %d  occupancy %d  LDS %6d" % (name, v.get("VGPRs", -1), v.get("VGPRs Spill", -1),
           v.get("ScratchSize", -1), v.get("Occupancy", -1), v.get("LDS Size", -1)))
