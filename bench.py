@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short SH23 / SHB23 lines appended to the default run")
     ap.add_argument("--no-host-vectors", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg of the kdyn workload")
     ap.add_argument("--replicas", action="store_true", help="N>1: run N independent gradients instead of the slab decomposition")
+    ap.add_argument("--devices", default=None, help="kdyn in ONE process over these GPUs (e.g. 0,1,2,3,4,5,6,7; a one-GPU box: 0,0): the multi-device "
+                    "context of smo_create_multi — full host vectors in and out, peer pulls instead of RCCL; not combinable with --gpus > 1")
     ap.add_argument("--allow-replica-fallback", action="store_true", help="N>1: if the slab-decomposed path fails, report independent replicas "
                     "(flagged in config.slab_path_error) instead of exiting non-zero")
     return ap.parse_args()
@@ -548,6 +550,55 @@ def bench_kdyn(a, torch, rank, world):
     return steps, warm, el, 1, roof, cfg, cpu
 
 
+def bench_kdyn_multi(a, torch, devices):
+    """ONE process, ONE context (smo_create_multi): the gradient slab-decomposed over `devices` with the reference's full host vectors."""
+    from spheremanopt_amd import _capi, kdyn
+    N = a.npts or 128
+    Rm, dt = 1.0, 1e-3
+    n_iters = a.iters or 1000
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup is not None else 1
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), dt, n_iters, Rm, devices, cost="Final", ckpt=0)
+    hX = [_capi.pinned_copy(B), _capi.pinned_copy(U)]
+    hG = [_capi.pinned_empty(B.size), _capi.pinned_empty(U.size)]
+    ctx.timing_enable(True)                                   # device 0's kernels: breakdown from the warm-up gradient
+    for _ in range(max(warm, 1)):
+        ctx.forward(hX); ctx.adjoint(None, out=hG)
+    tim = ctx.timing()
+    dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"] if tim[i]["hbm_bytes_per_launch"] > 0 else -1.0)
+    ex_i = [i for i, t in enumerate(tim) if t["kernel"].startswith("slab_exchange")]
+    ctx.timing_enable(select=[dom_i] + ex_i)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        J = ctx.forward(hX); ctx.adjoint(None, out=hG)
+    el = time.perf_counter() - t0
+    t2 = ctx.timing()
+    dom_k = t2[dom_i]
+    avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
+    ex = [t2[i] for i in ex_i]
+    roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms, "per_gpu": True, "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
+            "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1)} for t in tim]}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint" % (N, Rm, dt * n_iters, dt),
+           "grid": [G, G, G], "n_iters": n_iters, "J": J, "devices": list(devices),
+           "parallelism": "ONE process, slab x%d over devices %s (smo_create_multi: one worker thread per device, transposes = peer pulls "
+                          "with hipMemcpyPeerAsync ordered by HIP events; no RCCL)" % (len(devices), list(devices)),
+           "vectors": "host (pinned), the reference's full vectors: scatter of X and gather of grad J inside the timed region",
+           "checkpoint_interval": int(ctx.get(0)), "chunks": int(ctx.comm_get(0)),
+           "compute_ms_per_step_pair": sum(t["total_ms"] for t in tim if not t["kernel"].startswith("slab_exchange")) / max(warm, 1) / n_iters,
+           "exchange_ms_per_step_pair": (sum(t["total_ms"] for t in ex) / steps / n_iters) if ex else None,
+           "wall_ms_per_step_pair": 1e3 * el / steps / n_iters, "stack_GB": ctx.stack_bytes / 1e9}
+    fx = os.path.join(ROOT, "tests", "golden", "oracle_kdyn_c4_%d_n%d.npz" % (N, n_iters))
+    if os.path.exists(fx):
+        Jo = float(np.load(fx)["J_Final"])
+        cfg["J_oracle_fixture"], cfg["J_matches_oracle_1e-6"] = Jo, bool(abs(J - Jo) <= 1e-6 * abs(Jo))
+    ctx.close()
+    return steps, warm, el, 1, roof, cfg, None
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -606,7 +657,15 @@ def main():
         watchdog = threading.Timer(limit, _give_up)
         watchdog.daemon = True
         watchdog.start()
-    if wl == "sh23":
+    n_gpus_line = world
+    if a.devices:
+        if world > 1 or wl != "kdyn":
+            raise SystemExit("bench.py: --devices is the single-process form of the kdyn workload (no launcher, no --gpus > 1)")
+        devs = [int(d) for d in a.devices.split(",")]
+        steps, warm, el, per_step_units, roof, cfg, cpu = bench_kdyn_multi(a, torch, devs)
+        scaling, n_gpus_line = "strong", len(set(devs))
+        a.no_secondary = True
+    elif wl == "sh23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_sh23(a, torch, rank, world)
     elif wl == "shb23":
         steps, warm, el, per_step_units, roof, cfg, cpu = bench_shb23(a, torch, rank, world)
@@ -707,7 +766,7 @@ def main():
     if rank == 0:
         total = steps * per_step_units * world
         out = {"metric": "forward+adjoint gradient evals/sec", "value": total / el, "unit": "gradient evals/s",
-               "n_gpus": world, "rccl_ranks": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.get_backend() == "nccl") else 0),      # 0: no RCCL communicator exists in this run
+               "n_gpus": n_gpus_line, "rccl_ranks": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.get_backend() == "nccl") else 0),      # 0: no RCCL communicator exists in this run
                "backend": (torch.distributed.get_backend() if world > 1 else None),
                "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,

@@ -51,6 +51,17 @@ def test_kdyn_line_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
 
 
+def test_single_process_multi_device_line():
+    """`--devices 0,0`: the kdyn gradient through ONE multi-device context (smo_create_multi) in this one process, no launcher."""
+    d = _run(["--devices", "0,0", "--npts", "32", "--iters", "20", "--steps", "2", "--warmup", "1"])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["rccl_ranks"] == 0 and c["devices"] == [0, 0]
+    assert "ONE process" in c["parallelism"] and c["chunks"] >= 1
+    assert c["compute_ms_per_step_pair"] > 0 and c["exchange_ms_per_step_pair"] > 0 and c["wall_ms_per_step_pair"] > 0
+    one = _run(["--npts", "32", "--iters", "20", "--steps", "1", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"])
+    assert abs(c["J"] - one["config"]["J"]) <= 1e-12 * abs(one["config"]["J"])
+
+
 @pytest.mark.parametrize("wl", ["sh23", "shb23", "pois"])
 def test_other_workloads_emit_one_line(wl):
     d = _run(["--workload", wl, "--steps", "1", "--warmup", "1", "--iters", "40", "--no-cpu-baseline"])

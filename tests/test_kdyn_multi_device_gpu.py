@@ -68,6 +68,59 @@ def test_multi_device_context_with_checkpoint_windows():
     ck.close()
 
 
+@pytest.mark.parametrize("chunks,devs", [(2, [0, 0]), (3, [0, 0, 0, 0])])
+def test_multi_device_context_with_the_chunk_pipeline(chunks, devs, monkeypatch):
+    """SMO_SLAB_CHUNKS = K: the exchanges of the peer transport run chunk by chunk on the second stream, overlapped with the grid kernels
+    (the same pipeline as with RCCL); gradients equal the one-chunk run bit for bit."""
+    N, n, dt = 48, 5, 5e-3
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 5), kdyn.synthetic_field(G, 6)
+    res = []
+    for K in (1, chunks):
+        monkeypatch.setenv("SMO_SLAB_CHUNKS", str(K))
+        ctx = _capi.MultiContext(N, (0., 2. * np.pi), dt, n, 1.0, devs, cost="Integrated")
+        assert ctx.comm_get(0) == K
+        res.append((ctx.forward([B, U]), [g.copy() for g in ctx.adjoint(None)]))
+        ctx.close()
+    (J1, g1), (JK, gK) = res
+    assert JK == J1 and np.array_equal(gK[0], g1[0]) and np.array_equal(gK[1], g1[1])
+
+
+def test_multi_device_context_at_the_bench_grid_against_the_oracle_fixture():
+    """BASELINE config 4's grid (128^3, 50 of its 1000 steps) on four worker threads of one context against the committed oracle run."""
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c4_128_n50.npz"))
+    N, n = 128, 50
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), 1e-3, n, 1.0, [0, 0, 0, 0])
+    J = ctx.forward([B, U])
+    g = ctx.adjoint(None)
+    assert abs(J - float(gold["J_Final"])) <= RTOL * abs(float(gold["J_Final"]))
+    idx = gold["idx"]
+    for name, v in (("gB", g[0]), ("gU", g[1])):
+        ref = gold["Final_Discrete_" + name]
+        assert np.linalg.norm(v[idx] - ref) <= RTOL * np.linalg.norm(ref), name
+        nrm = float(gold["Final_Discrete_%s_norm" % name])
+        assert abs(np.linalg.norm(v) - nrm) <= RTOL * nrm
+    ctx.close()
+
+
+def test_null_transport_runs_one_ranks_share():
+    """smo_comm_set_transport(ctx, NULL, NULL, NULL): rank 0 of a 4-way decomposition runs its kernels through the real in-library loop with no
+    exchange at all (tools/prof_slab_geometry.py); results are meaningless, the call sequence must simply complete and be timed."""
+    ctx = _capi.Context(_capi.SMO_KDYN, 32, (0., 2. * np.pi), 1e-3, 4, 1.0, rank=0, world=4)
+    _capi._check(_capi.lib().smo_comm_set_transport(ctx._h, _capi.ALLTOALL_FN(), _capi.ALLREDUCE_FN(), None))
+    x = np.full(ctx.vec_len, 1e-3)
+    ctx.timing_enable(True)
+    J = ctx.forward([x, x]); g = ctx.adjoint(None)
+    assert np.isfinite(J) and len(g) == 2 and g[0].shape == (ctx.vec_len,)
+    tim = {t["kernel"]: t["launches"] for t in ctx.timing()}
+    assert tim["slab_exchange(all-to-all)"] >= 16 and tim["kd_x_pass<fused_adj>"] == 4
+    ctx.close()
+
+
 def test_reference_callbacks_on_a_multi_device_domain():
     """The drop-in surface: the reference's callbacks + optimiser in ONE process over a slab-decomposed context, no launcher."""
     from spheremanopt_amd.sphere_opt import Optimise_On_Multi_Sphere
