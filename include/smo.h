@@ -104,8 +104,8 @@ int         smo_create(const smo_config* cfg, smo_ctx** out);
  *       [3][G][G][G/ndev] in the HBM of dev_ids[i];
  * inside, one worker thread per device runs the same in-library time loop as with one process per GPU, and a transpose is every device pulling
  * its blocks from its peers with hipMemcpyPeerAsync (peer access over xGMI), ordered by HIP events — no RCCL, no launcher, nothing for the
- * caller to set up.  The same device may be listed more than once (tests on a one-GPU box).  smo_snapshot_read and smo_inner_dev are not
- * available on such a context; smo_timing_* report device 0's kernels. */
+ * caller to set up.  The same device may be listed more than once (tests on a one-GPU box).  smo_snapshot_read is not available on such a
+ * context, smo_inner_dev is replaced by smo_inner_slabs; smo_timing_* report device 0's kernels. */
 int         smo_create_multi(const smo_config* cfg, int ndev, const int* dev_ids, smo_ctx** out);
 void        smo_destroy(smo_ctx* ctx);
 const char* smo_last_error(void);
@@ -132,6 +132,9 @@ int smo_inner(smo_ctx* ctx, const double* x, const double* y, double* out);
 int smo_forward_dev(smo_ctx* ctx, const double* const* X_dev, double* J_host);
 int smo_adjoint_dev(smo_ctx* ctx, const double* const* X_dev, int adjoint_type, double* const* grad_dev);
 int smo_inner_dev(smo_ctx* ctx, const double* x_dev, const double* y_dev, double* out_host);
+/* <x,y> of device-resident vectors given slab by slab: x_slabs[i] / y_slabs[i] = the slab in the HBM of the i-th device of a multi-device
+ * context (smo_create_multi; the layout smo_forward_dev takes per component); a plain context has one slab, the vector itself. */
+int smo_inner_slabs(smo_ctx* ctx, const double* const* x_slabs, const double* const* y_slabs, double* out_host);
 
 /* ---- device-resident vectors for the caller's own vector algebra ------------------------------------------------
  * The reference's optimiser does X + alpha*d, coeff*X, -1.*g + beta*t and deepcopy on full-size NumPy vectors

@@ -20,7 +20,7 @@ ERR_NAMES = {1: "SMO_ERR_ARG", 2: "SMO_ERR_NO_DEVICE", 3: "SMO_ERR_HIP", 4: "SMO
 
 EXPORTS = [
     "smo_create", "smo_create_multi", "smo_destroy", "smo_last_error", "smo_version", "smo_device_count", "smo_ncomp", "smo_vec_len",
-    "smo_stack_bytes", "smo_get", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev",
+    "smo_stack_bytes", "smo_get", "smo_forward", "smo_adjoint", "smo_inner", "smo_forward_dev", "smo_adjoint_dev", "smo_inner_dev", "smo_inner_slabs",
     "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get", "smo_timing_hbm_bytes",
     "smo_vec_alloc", "smo_vec_free", "smo_vec_pool_release", "smo_vec_pool_bytes", "smo_vec_upload", "smo_vec_download", "smo_vec_axpby",
     "smo_host_alloc", "smo_host_free",
@@ -93,6 +93,7 @@ def lib():
         getattr(L, name).argtypes = [vp, pp, C.c_int, pp]
     for name in ("smo_inner", "smo_inner_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, dp]
+    L.smo_inner_slabs.argtypes = [vp, pp, pp, dp]
     L.smo_snapshot_read.argtypes = [vp, C.c_int, C.c_int, dp]
     L.smo_transform.argtypes = [vp, C.c_int, vp, vp]
     L.smo_kdyn_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, dp]
@@ -309,8 +310,8 @@ class Context:
         if X is not None:
             self._check_dev(X, "adjoint_dev")
         self._check_dev(grads, "adjoint_dev(grads)")
-        _check(lib().smo_adjoint_dev(self._h, _ptr_array([_dev_ptr(x) for x in X]), ADJOINT[adjoint_type],
-                                     _ptr_array([_dev_ptr(g) for g in grads])))
+        xp = _ptr_array([_dev_ptr(x) for x in X]) if X is not None else _ptr_array([None] * len(grads))     # the adjoint replays the stack: X is not read
+        _check(lib().smo_adjoint_dev(self._h, xp, ADJOINT[adjoint_type], _ptr_array([_dev_ptr(g) for g in grads])))
         return grads
 
     def inner_dev(self, x, y):
@@ -443,3 +444,37 @@ class MultiContext(Context):
         want = (2 if who == "inner" else self.ncomp) * len(self.devices)
         if len(vecs) != want:
             raise ValueError("%s: %d slab pointers given, %d components x %d devices expected" % (who, len(vecs), self.ncomp, len(self.devices)))
+
+    # -- vectors that stay distributed over the devices (devvec.MultiDeviceVector): no PCIe traffic, no host algebra on full-size vectors --------
+    @staticmethod
+    def _on_device(v):
+        return hasattr(v, "slabs")
+
+    def _slab_ptrs(self, X):
+        for x in X:
+            if [s.device for s in x.slabs] != self.devices or sum(s.n for s in x.slabs) != self.vec_len:
+                raise ValueError("MultiDeviceVector does not match the context (devices %s, %d entries)" % (self.devices, self.vec_len))
+        return [s for x in X for s in x.slabs]                 # component-major: X[c * ndev + i]
+
+    def forward_any(self, X):
+        return self.forward_dev(self._slab_ptrs(X)) if self._on_device(X[0]) else self.forward(X)
+
+    def adjoint_any(self, X, adjoint_type="Discrete"):
+        if X is not None and len(X) and self._on_device(X[0]):
+            from .devvec import MultiDeviceVector
+            grads = [MultiDeviceVector.like(X[0]) for _ in range(self.ncomp)]
+            self.adjoint_dev(None, self._slab_ptrs(grads), adjoint_type)
+            return grads
+        return self.adjoint(None, adjoint_type)
+
+    def inner_any(self, x, y):
+        dx, dy = self._on_device(x), self._on_device(y)
+        if dx != dy:
+            raise TypeError("inner product: one operand is a MultiDeviceVector and the other is not")
+        if not dx:
+            return self.inner(x, y)
+        self._slab_ptrs([x, y])
+        out = np.zeros(1)
+        _check(lib().smo_inner_slabs(self._h, _ptr_array([_dev_ptr(s) for s in x.slabs]), _ptr_array([_dev_ptr(s) for s in y.slabs]),
+                                     out.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(out[0])

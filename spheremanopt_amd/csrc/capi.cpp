@@ -154,6 +154,13 @@ int smo_inner_dev(smo_ctx* ctx, const double* x, const double* y, double* out) {
     return ctx->impl->inner_dev(x, y, out);
 }
 
+int smo_inner_slabs(smo_ctx* ctx, const double* const* x, const double* const* y, double* out) {
+    CHECK_CTX(ctx);
+    if (!x || !y || !out || !x[0] || !y[0]) { smo::set_error("smo_inner_slabs: null argument"); return SMO_ERR_ARG; }
+    SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
+    return ctx->impl->inner_slabs(x, y, out);
+}
+
 int smo_snapshot_len(const smo_ctx* ctx, size_t* n) {
     CHECK_CTX(ctx);
     if (!n) return SMO_ERR_ARG;

@@ -124,8 +124,14 @@ public:
     }
     int inner_dev(const double* x, const double* y, double* out) override {
         (void)x; (void)y; (void)out;
-        set_error("smo_inner_dev on a multi-device context: pass host vectors (smo_inner) or per-device slabs through smo_forward_dev's layout");
+        set_error("smo_inner_dev on a multi-device context: pass host vectors (smo_inner) or one slab pointer per device (smo_inner_slabs)");
         return SMO_ERR_UNSUPPORTED;
+    }
+    int inner_slabs(const double* const* x, const double* const* y, double* out) override {
+        std::vector<double> oi(W, 0.0);
+        SMO_TRY(on_all([&](int i) { return r[i]->inner_dev(x[i], y[i], &oi[i]); }));      // reduced over the ranks inside (collective)
+        *out = oi[0];
+        return SMO_OK;
     }
 
     // ---- the reference's callbacks: full host vectors in, full host vectors out ------------------------------------------------

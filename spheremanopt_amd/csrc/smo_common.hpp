@@ -135,6 +135,8 @@ public:
     virtual int forward_dev(const double* const* X, double* J_host) = 0;
     virtual int adjoint_dev(const double* const* X, int adjoint_type, double* const* grad) = 0;
     virtual int inner_dev(const double* x, const double* y, double* out_host) = 0;
+    // <x,y> of vectors given slab by slab (one pointer per device of a multi-device context; a plain context has one slab: the vector)
+    virtual int inner_slabs(const double* const* x, const double* const* y, double* out_host) { return inner_dev(x[0], y[0], out_host); }
     virtual int snapshot_read(int b, int index, double* out) = 0;
     virtual int transform_host(int which, const double* in, double* out) {
         (void)which; (void)in; (void)out;

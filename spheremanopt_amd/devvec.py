@@ -108,13 +108,100 @@ class DeviceVector:
         return "DeviceVector(n=%d, device=%d)" % (self.n, self.device)
 
 
+class MultiDeviceVector:
+    """A vector of a multi-device context (smo_create_multi) that STAYS distributed: one DeviceVector per device holding that device's z slab
+    [3][G][G][G/W] of the reference's flat vector [3][G][G][G].  The same algebra as DeviceVector, slab by slab (the operations the optimiser
+    uses are elementwise, so the slab layout does not matter to them); `numpy()` gathers the reference's layout."""
+
+    __array_ufunc__ = None
+
+    def __init__(self, slabs, G):
+        self.slabs, self.G = list(slabs), int(G)
+
+    @classmethod
+    def from_numpy(cls, x, devices):
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        G = int(round((x.size / 3) ** (1. / 3.)))
+        W = len(devices)
+        if 3 * G ** 3 != x.size or G % W:
+            raise ValueError("MultiDeviceVector: %d entries are not three fields on a grid that %d devices divide" % (x.size, W))
+        f = x.reshape(3, G, G, G)
+        Gz = G // W
+        return cls([DeviceVector.from_numpy(np.ascontiguousarray(f[..., i * Gz:(i + 1) * Gz]), d) for i, d in enumerate(devices)], G)
+
+    @classmethod
+    def like(cls, v):
+        return cls([DeviceVector(s.n, s.device) for s in v.slabs], v.G)
+
+    def numpy(self):
+        W = len(self.slabs)
+        Gz = self.G // W
+        out = np.empty((3, self.G, self.G, self.G))
+        for i, s in enumerate(self.slabs):
+            out[..., i * Gz:(i + 1) * Gz] = s.numpy().reshape(3, self.G, self.G, Gz)
+        return out.reshape(-1)
+
+    @property
+    def size(self):
+        return sum(s.n for s in self.slabs)
+
+    @property
+    def shape(self):
+        return (self.size,)
+
+    def _zip(self, o, f):
+        if not isinstance(o, MultiDeviceVector):
+            return NotImplemented
+        if len(o.slabs) != len(self.slabs):
+            raise ValueError("MultiDeviceVector: different numbers of slabs")
+        return MultiDeviceVector([f(a, b) for a, b in zip(self.slabs, o.slabs)], self.G)
+
+    def _map(self, f):
+        return MultiDeviceVector([f(a) for a in self.slabs], self.G)
+
+    def __add__(self, o):
+        return self._zip(o, lambda a, b: a + b)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._zip(o, lambda a, b: a - b)
+
+    def __mul__(self, s):
+        return self._map(lambda a: a * s) if isinstance(s, numbers.Real) else NotImplemented
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, s):
+        return self._map(lambda a: a / s) if isinstance(s, numbers.Real) else NotImplemented
+
+    def __neg__(self):
+        return self._map(lambda a: -a)
+
+    def copy(self):
+        return self._map(lambda a: a.copy())
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
+    __copy__ = copy
+
+    def __repr__(self):
+        return "MultiDeviceVector(n=%d, devices=%s)" % (self.size, [s.device for s in self.slabs])
+
+
+def to_devices(X, devices):
+    """List of NumPy vectors -> list of MultiDeviceVectors distributed over `devices` (the X_0 of an optimisation on a multi-device domain)."""
+    return [x if isinstance(x, MultiDeviceVector) else MultiDeviceVector.from_numpy(x, devices) for x in X]
+
+
 def to_device(X, device=0):
     """List of NumPy vectors -> list of DeviceVectors (the optimiser's X_0)."""
     return [x if isinstance(x, DeviceVector) else DeviceVector.from_numpy(x, device) for x in X]
 
 
 def to_host(X):
-    return [x.numpy() if isinstance(x, DeviceVector) else np.asarray(x) for x in X]
+    return [x.numpy() if isinstance(x, (DeviceVector, MultiDeviceVector)) else np.asarray(x) for x in X]
 
 
 def pool_bytes(device=0):

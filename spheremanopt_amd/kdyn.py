@@ -204,8 +204,8 @@ def FWD_Solve_IVP_Lin(X0, domain, Rm, dt, N_ITERS, N_SUB_ITERS, X_FWD_DICT, Cost
     """-J(B0, U): J = <B_N,B_N> ("Final") or dt*sum_n <B_n,B_n> ("Integrated"); fills the device snapshot stack."""
     _check_window(N_ITERS, N_SUB_ITERS)
     ctx = domain.context(Rm, dt, N_ITERS, Cost_function)
-    on_device = isinstance(X0[0], DeviceVector)             # vectors already in HBM (devvec.py): no staging copies
-    J = ctx.forward_dev([X0[0], X0[1]]) if on_device else ctx.forward([X0[0], X0[1]])
+    on_device = hasattr(X0[0], "numpy")                     # vectors already in HBM (devvec.py DeviceVector / MultiDeviceVector): no staging copies
+    J = ctx.forward_any([X0[0], X0[1]])
     for k in ('A_fwd', 'B_fwd', 'C_fwd'):
         X_FWD_DICT[k].ctx = ctx
     if getattr(domain, "write_products", False):           # scalar_data/ and CheckPoints/ like the reference's file handlers

@@ -141,6 +141,31 @@ def test_reference_callbacks_on_a_multi_device_domain():
     assert rel(X2[0], X1[0]) < 1e-8 and rel(X2[1], X1[1]) < 1e-8
 
 
+def test_optimiser_on_distributed_device_vectors():
+    """devvec.MultiDeviceVector: the optimiser's vectors stay distributed over the devices of the context (no PCIe traffic, no NumPy algebra
+    on full-size vectors); the iterate sequence equals the one on NumPy vectors through the same multi-device context."""
+    from spheremanopt_amd.devvec import MultiDeviceVector, to_devices, to_host
+    from spheremanopt_amd.sphere_opt import Optimise_On_Multi_Sphere
+    N, n, dt, devs = 16, 8, 5e-3, [0, 0]
+    dom = kdyn.KDynDomain(N, devices=devs)
+    G = dom.G
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    v = MultiDeviceVector.from_numpy(B, devs)
+    assert np.array_equal(v.numpy(), B) and np.array_equal((v + 0.5 * v).numpy(), B + 0.5 * B) and np.array_equal((-v).numpy(), -B)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    args_f = [dom, 1.0, dt, n, n, buf, "Final", "Discrete"]
+    res = []
+    for X0 in ([B, U], to_devices([B, U], devs)):
+        R, F, X = Optimise_On_Multi_Sphere(X0, [1.0, 1.0], kdyn.FWD_Solve_IVP_Lin, kdyn.ADJ_Solve_IVP_Lin, kdyn.Inner_Prod_3,
+                                            args_f=args_f, args_IP=(dom, None), max_iters=3, alpha_k=1., LS='LS_wolfe', CG=True, verbose=False)
+        res.append((R, F, to_host(X)))
+    (R1, F1, X1), (R2, F2, X2) = res
+    assert isinstance(res[1][2][0], np.ndarray) and len(F1) == len(F2)
+    assert np.allclose(F1, F2, rtol=1e-12, atol=0) and np.allclose(R1, R2, rtol=1e-9)
+    assert rel(X2[0], X1[0]) < 1e-11 and rel(X2[1], X1[1]) < 1e-11
+    dom.drop_contexts()
+
+
 def test_errors():
     with pytest.raises(_capi.SmoError):
         _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 4, 1.0, [0, 0, 0])           # 3 devices do not divide a = 8
