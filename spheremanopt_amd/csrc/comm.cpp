@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -127,6 +128,18 @@ int SlabComm::set_peers(int r, PeerGroup* g) {
 }
 
 // ---- PeerGroup: ranks = threads of one process, one GPU each ---------------------------------------------------------------
+// The pull of one exchange as ONE kernel: with peer access enabled a rank reads its blocks straight out of its W - 1 peers' send buffers (xGMI
+// loads) and writes them to its own receive buffer; blockIdx.y walks the peers (starting with the rank itself, so that at any moment the ranks
+// read from different sources), blockIdx.x strides over a block.  All links of the GPU carry traffic at once — W - 1 hipMemcpyPeerAsync calls on
+// one stream would run one after the other, one link at a time — and an exchange costs the host one launch instead of W - 1 copies.
+struct PeerSrcs { const double2* p[64]; };
+__global__ __launch_bounds__(256) void peer_gather(double2* __restrict__ dst, PeerSrcs srcs, int W, int rank, size_t n2) {
+    const int p = (rank + (int)blockIdx.y) % W;
+    const double2* __restrict__ from = srcs.p[p] + (size_t)rank * n2;
+    double2* __restrict__ to = dst + (size_t)p * n2;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) to[i] = from[i];
+}
+
 PeerGroup::PeerGroup(const std::vector<int>& devices) : dev(devices) {
     const int W = (int)dev.size();
     pub_src.assign(W, nullptr); pub_dst.assign(W, nullptr);
@@ -146,6 +159,9 @@ PeerGroup::PeerGroup(const std::vector<int>& devices) : dev(devices) {
             (void)hipGetLastError();
         }
     }
+    // the gather kernel needs peer access between every pair of distinct devices; SMO_PEER_COPY=memcpy forces the copy calls (which do not)
+    const char* e = getenv("SMO_PEER_COPY");
+    use_kernel = peer_access && !(e && std::string(e) == "memcpy");
 }
 PeerGroup::~PeerGroup() {
     for (size_t r = 0; r < dev.size(); ++r) {
@@ -177,13 +193,23 @@ int PeerGroup::alltoall(int rank, const void* src, void* dst, size_t bytes, hipS
     pub_src[rank] = src; pub_dst[rank] = dst;
     SMO_HIP(hipEventRecord(ev_ready[rank], s));
     SMO_TRY(barrier());
-    for (int q = 0; q < W; ++q) {
-        const int p = (rank + q) % W;                        // start with my own block, then walk the ring: the peers pull from different sources
+    for (int p = 0; p < W; ++p)
         if (p != rank) SMO_HIP(hipStreamWaitEvent(s, ev_ready[p], 0));
-        const char* from = static_cast<const char*>(pub_src[p]) + (size_t)rank * bytes;
-        char* to = static_cast<char*>(dst) + (size_t)p * bytes;
-        if (dev[p] == dev[rank]) SMO_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
-        else SMO_HIP(hipMemcpyPeerAsync(to, dev[rank], from, dev[p], bytes, s));
+    if (use_kernel && bytes % 16 == 0 && W <= 64) {
+        PeerSrcs srcs{};
+        for (int p = 0; p < W; ++p) srcs.p[p] = static_cast<const double2*>(pub_src[p]);
+        const size_t n2 = bytes / 16;
+        const unsigned gx = (unsigned)std::min<size_t>(128, (n2 + 255) / 256);
+        hipLaunchKernelGGL(peer_gather, dim3(gx, W), dim3(256), 0, s, static_cast<double2*>(dst), srcs, W, rank, n2);
+        SMO_HIP(hipGetLastError());
+    } else {
+        for (int q = 0; q < W; ++q) {
+            const int p = (rank + q) % W;                    // start with my own block, then walk the ring: the peers pull from different sources
+            const char* from = static_cast<const char*>(pub_src[p]) + (size_t)rank * bytes;
+            char* to = static_cast<char*>(dst) + (size_t)p * bytes;
+            if (dev[p] == dev[rank]) SMO_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
+            else SMO_HIP(hipMemcpyPeerAsync(to, dev[rank], from, dev[p], bytes, s));
+        }
     }
     SMO_HIP(hipEventRecord(ev_pulled[rank], s));
     SMO_TRY(barrier());

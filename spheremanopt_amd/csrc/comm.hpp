@@ -17,11 +17,12 @@
 namespace smo {
 
 // Third transport: the ranks are contexts of ONE process, each driven by its own host thread on its own GPU (smo_create_multi, csrc/multi.cpp).
-// A transpose is then W pulls per rank over the node's point-to-point links, hipMemcpyPeerAsync from every peer's send buffer on the rank's
-// own stream, ordered by HIP events — no RCCL, no second process:
+// A transpose is then every rank pulling its W blocks over the node's point-to-point links straight out of the peers' send buffers (peer
+// access), on the rank's own stream, ordered by HIP events — no RCCL, no second process:
 //   rank r:  publish (src, dst), record ev_ready[r] on its stream           (everything enqueued so far: src produced, dst consumed)
 //            -- host barrier: every rank has recorded --
-//            for every peer p: wait ev_ready[p]; copy p's block for me (src_p + r * bytes, device p) -> dst + p * bytes
+//            wait ev_ready[p] of every peer; ONE gather kernel reads my block out of every peer's send buffer (src_p + r * bytes, over
+//            xGMI, all links at once) into dst + p * bytes        [SMO_PEER_COPY=memcpy / no peer access: W hipMemcpyPeerAsync calls]
 //            record ev_pulled[r]
 //            -- host barrier --
 //            wait ev_pulled[p] of every peer: from here on my src may be overwritten
@@ -38,6 +39,7 @@ public:
     void reset();                       // before a new collective call sequence (all ranks idle)
     std::vector<int> dev;
     bool peer_access = false;           // hipDeviceEnablePeerAccess succeeded for every pair of distinct devices
+    bool use_kernel = false;            // pulls as one gather kernel reading the peers' buffers directly (else hipMemcpyPeerAsync calls)
 
 private:
     int barrier();                      // SMO_OK, or SMO_ERR_STATE when a rank has failed
