@@ -51,7 +51,6 @@ struct Geom {
     int tyl;      // layout of Ty: 0 = planes [c][kx][y][z] (+ padding per plane), 1 = z-block major [c][z/8][kx][y][z%8] (below)
     int ykx;      // y pass, z-block-major Ty: 1 = consecutive workgroups take consecutive kx (their G*128-byte blocks are adjacent)
     size_t tyk;   // z-block major: elements between consecutive kx blocks (8 G + one 128-byte line of padding)
-    int sub0, subn;   // z-block-major Ty only: this launch of a y / fused x pass covers the z blocks [sub0, sub0 + subn) (subn = 0: all of them)
     double Rm, dt;
 };
 
@@ -336,15 +335,15 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     const int tid = threadIdx.x;
     for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
     __syncthreads();
-    const int ntile = g.subn ? g.subn : (g.Gzl + ZT - 1) / ZT;           // z tiles of this launch (a sub-range: whole z blocks, ZT = 8)
+    const int ntile = (g.Gzl + ZT - 1) / ZT;
     int c, kx, z0;
     if (g.tyl && g.ykx) {                       // consecutive workgroups: consecutive kx of one (c, z tile) — adjacent blocks of Ty
         kx = blockIdx.x % g.a;
         const int r = blockIdx.x / g.a;
-        c = r / ntile; z0 = (g.sub0 + r - c * ntile) * ZT;
+        c = r / ntile; z0 = (r - c * ntile) * ZT;
     } else {
         const int o = blockIdx.x / ntile;       // o = c * a + kx
-        z0 = (g.sub0 + blockIdx.x - o * ntile) * ZT;
+        z0 = (blockIdx.x - o * ntile) * ZT;
         c = o / g.a; kx = o - c * g.a;
     }
     const size_t zrow = ys_row0(c, kx, g) + z0;                               // + idx * Gzl + b
@@ -779,9 +778,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FU
         const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);
         tile = (size_t)q * (8 * PAIRED) + PAIRED * (r % 8) + r / 8;
     }
-    if constexpr (T <= 8) {
-        if (g.tyl) tile += (size_t)g.sub0 * g.G * (8 / T);      // a sub-range launch starts at its first z block (tiles are walked z-block major)
-    }
     size_t i0 = tile * T;
     if constexpr (T <= 8) {
         if (g.tyl) {
@@ -973,7 +969,6 @@ public:
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
-        { const char* e = getenv("SMO_KD_SPLIT"); if (e) split = atoi(e); }
         if (any_size) {
             fuse_next = false;                               // the run-time-length update kernel has no fused next pass
             plan = any_plan(3 * N / 2);
@@ -1178,8 +1173,6 @@ public:
         // z-block-major Ty: the inverse pass (reads Tz, WRITES Ty) takes its workgroups kx-fastest — adjacent blocks of Ty are written together
         // (256^3: 315 -> 289 us) —, the forward pass (reads Ty, writes Tz) z-fastest (265 vs 271 us kx-fastest); SMO_KD_YKX = 0 / 1 forces one order
         q.ykx = ykx_env >= 0 ? ykx_env : (inv ? 1 : 0);
-        q.sub0 = sub_lo; q.subn = sub_n;
-        hipStream_t stream = lstream ? lstream : this->stream;       // (a half of the grid stage may run on the side stream: grid_halves)
         if (!inv && ys == zs) zs_ready_fwd = zs_ready_adj = -1;      // one GPU: the y pass writes the buffer the z pass reads
         cplx* ex = ys + (size_t)k * q.cblk + (size_t)f * tzc;
         if (any_size) {
@@ -1195,7 +1188,7 @@ public:
             ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
             auto launch = [&](auto zt) {
                 constexpr int ZT = decltype(zt)::value;
-                const int nwg = 3 * g.a * (sub_n ? sub_n : (g.Gzl + ZT - 1) / ZT);
+                const int nwg = 3 * g.a * ((g.Gzl + ZT - 1) / ZT);
                 if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, ty, d_tw, q);
                 else hipLaunchKernelGGL((kd_y_pass<L, false, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ty, ex, d_tw, q);
             };
@@ -1208,10 +1201,8 @@ public:
     // chunk `k` of the grid stage.  vec_in / vec_out: caller-layout grid vectors (X_FROM_GRID / X_TO_GRID); vec_out == nullptr with
     // X_TO_GRID writes the internal (tile-major) U field.  inA / inB: read the spectra of field group A / B from elsewhere (the Ty stack).
     int x_pass(int mode, int k, const double* vec_in, double* vec_out, const cplx* inA = nullptr, const cplx* inB = nullptr) {
-        const size_t plane = sub_n ? (size_t)g.G * 8 * sub_n : (size_t)g.G * g.Gzl;      // (y,z) points of this launch
+        const size_t plane = (size_t)g.G * g.Gzl;
         Geom q = geom(1, k);
-        q.sub0 = sub_lo; q.subn = sub_n;
-        hipStream_t stream = lstream ? lstream : this->stream;
         const bool to_U = (mode == X_TO_GRID && vec_out == nullptr);
         q.utile = to_U ? 1 : 0;
         double* Uk = d_U + (size_t)k * ngc;
@@ -1299,46 +1290,12 @@ public:
     bool adj_cont = false;
     bool fuse_next = true;                     // SMO_KD_FUSE_NEXT=0: separate kernels (ablation)
     bool adj_seq = true;                       // SMO_KD_ADJ_SEQ=0: adjoint x pass with both field groups in the tile at once
-    // ---- experiment (SMO_KD_SPLIT=2, one GPU, z-block-major Ty): the grid stage in two halves of the z blocks on two streams, staggered so
-    // that half 1's inverse y pass overlaps half 0's fused x pass and half 0's forward y pass overlaps half 1's x pass (different kernels
-    // mix on a CU: an occupancy-bound x pass beside a streaming y pass).  No layout changes: a half is a sub-range of the y pass's z tiles
-    // and of the x pass's tiles, which are walked z-block major.
-    int split = 1, sub_lo = 0, sub_n = 0;
-    hipStream_t lstream = nullptr, sstream = nullptr;
-    hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
-    bool can_split() const { return split == 2 && g.tyl && K == 1 && !any_size && cfg.world == 1 && !force_exchange && (g.Gzl / 8) % 2 == 0 && g.Gzl / 8 >= 4; }
-    template <class F1, class F2> int grid_halves(F1 first, F2 rest) {
-        if (!sstream) {
-            SMO_HIP(hipStreamCreateWithFlags(&sstream, hipStreamNonBlocking));
-            SMO_HIP(hipEventCreateWithFlags(&ev_h0, hipEventDisableTiming));
-            SMO_HIP(hipEventCreateWithFlags(&ev_h1, hipEventDisableTiming));
-        }
-        const int nb = g.Gzl / 8, h = nb / 2;
-        int rc = SMO_OK;
-        sub_lo = 0; sub_n = h; lstream = stream;
-        rc = first();
-        if (rc == SMO_OK && hipEventRecord(ev_h0, stream) != hipSuccess) rc = SMO_ERR_HIP;
-        if (rc == SMO_OK && hipStreamWaitEvent(sstream, ev_h0, 0) != hipSuccess) rc = SMO_ERR_HIP;
-        sub_lo = h; sub_n = nb - h; lstream = sstream;
-        if (rc == SMO_OK) rc = first();
-        if (rc == SMO_OK) rc = rest();
-        if (rc == SMO_OK && hipEventRecord(ev_h1, sstream) != hipSuccess) rc = SMO_ERR_HIP;
-        sub_lo = 0; sub_n = h; lstream = stream;
-        if (rc == SMO_OK) rc = rest();
-        if (rc == SMO_OK && hipStreamWaitEvent(stream, ev_h1, 0) != hipSuccess) rc = SMO_ERR_HIP;
-        sub_lo = 0; sub_n = 0; lstream = nullptr;
-        if (rc == SMO_ERR_HIP) set_error("KDYN: stream / event call of the split grid stage failed");
-        return rc;
-    }
     int fwd_A(int n) {
         if (zs_ready_fwd == n) { zs_ready_fwd = -1; return SMO_OK; }
         return z_inverse(ZI_PLAIN, snap(n), 0, 1);
     }
     int fwd_B(int n, int k) {
         cplx* ty = have_ty(n) ? tyslot(n, k) : tyw(0, k);
-        if (can_split())
-            return grid_halves([&]() { return y_pass(true, 0, 1, ty, k); },
-                               [&]() { SMO_TRY(x_pass(X_FUSED_FWD, k, nullptr, nullptr, ty)); return y_pass(false, 0, 1, tyw(0, k), k); });
         SMO_TRY(y_pass(true, 0, 1, ty, k));
         SMO_TRY(x_pass(X_FUSED_FWD, k, nullptr, nullptr, ty));
         return y_pass(false, 0, 1, tyw(0, k), k);
@@ -1369,9 +1326,6 @@ public:
     }
     int adj_B(int idx, int k) {
         const int nf = adj_groups(idx);
-        if (can_split())
-            return grid_halves([&]() { SMO_TRY(y_pass(true, 0, nf, tyw(0, k), k)); return nf == 2 ? y_pass(true, 1, 2, tyw(1, k), k) : SMO_OK; },
-                               [&]() { SMO_TRY(x_pass(X_FUSED_ADJ, k, nullptr, nullptr, nullptr, nf == 1 ? tyslot(idx, k) : nullptr)); return y_pass(false, 0, 1, tyw(0, k), k); });
         SMO_TRY(y_pass(true, 0, nf, tyw(0, k), k));
         if (nf == 2) SMO_TRY(y_pass(true, 1, 2, tyw(1, k), k));
         SMO_TRY(x_pass(X_FUSED_ADJ, k, nullptr, nullptr, nullptr, nf == 1 ? tyslot(idx, k) : nullptr));
@@ -1431,8 +1385,6 @@ public:
         if (stream) (void)hipStreamSynchronize(stream);
         drop_graphs();
         if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
-        if (sstream) { (void)hipStreamSynchronize(sstream); (void)hipStreamDestroy(sstream); }
-        for (hipEvent_t e : {ev_h0, ev_h1}) if (e) (void)hipEventDestroy(e);
         if (ev_main) (void)hipEventDestroy(ev_main);
         for (auto* v : {&ev_in, &ev_ph, &ev_out}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     }
