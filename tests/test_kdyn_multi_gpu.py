@@ -73,3 +73,28 @@ def test_in_library_loop_over_rccl_between_gpus(tmp_path, N, cost, adj, ckpt, ch
     assert abs(float(r["J"]) - Jo) <= 1e-6 * abs(Jo)
     assert rel(r["gB"], goB) < 1e-6 and rel(r["gU"], goU) < 1e-6
     assert abs(float(r["ip"]) - o.inner(r["B"], goB)) <= 1e-6 * abs(o.inner(r["B"], goB))
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs at least two GPUs on the node (peer pulls between different devices)")
+@pytest.mark.parametrize("pull", ["kernel", "memcpy"])
+@pytest.mark.parametrize("N,cost,adj,ckpt,chunks", [(32, "Final", "Discrete", 1, 1), (64, "Integrated", "Continuous", 1, 2), (32, "Final", "Discrete", 3, 1)])
+def test_single_process_multi_device_context_between_gpus(N, cost, adj, ckpt, chunks, pull, monkeypatch):
+    """smo_create_multi over DIFFERENT devices: ONE process, one worker thread per GPU, the transposes as pulls out of the peers' send buffers
+    over xGMI (the gather kernel with peer access, or hipMemcpyPeerAsync calls) — against the oracle."""
+    from oracle.kdyn import KDynOracle
+    from spheremanopt_amd import _capi, kdyn
+    monkeypatch.setenv("SMO_PEER_COPY", pull)
+    monkeypatch.setenv("SMO_SLAB_CHUNKS", str(chunks))
+    W = 4 if (_ngpu() >= 4 and (N // 2) % 4 == 0) else 2
+    n = 4
+    G = 3 * N // 2
+    B = kdyn.synthetic_field(G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * G ** 3)
+    U = kdyn.synthetic_field(G, 2)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), 1e-2, n, 1.3, list(range(W)), cost=cost, ckpt=ckpt)
+    J = ctx.forward([B, U]); gB, gU = ctx.adjoint(None, adj)
+    o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
+    Jo = o.forward([B, U]); goB, goU = o.adjoint([B, U], adj)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))      # noqa: E731
+    assert abs(J - Jo) <= 1e-6 * abs(Jo) and rel(gB, goB) < 1e-6 and rel(gU, goU) < 1e-6
+    assert abs(ctx.inner(B, gB) - o.inner(B, goB)) <= 1e-6 * abs(o.inner(B, goB))
+    ctx.close()
