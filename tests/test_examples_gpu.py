@@ -16,6 +16,18 @@ def test_kdyn_script_at_the_reference_default_resolution(in_tmp_cwd):
     assert len(X) == 2 and X[0].shape == (3 * 36 ** 3,)
 
 
+def test_kdyn_script_in_one_process_over_several_devices(in_tmp_cwd):
+    """The same script with --devices 0,0 (the multi-device context, the box's GPU listed twice) and the optimiser's vectors distributed over
+    the devices: the same J_k sequence as the one-GPU run."""
+    from spheremanopt_amd.examples import kdyn_optimise
+    base = ["--npts", "24", "--dt", "5e-4", "--steps", "40", "--max-iters", "2", "--quiet"]
+    _, F1, X1, _ = kdyn_optimise.main(base)
+    _, F2, X2, _ = kdyn_optimise.main(base + ["--devices", "0,0", "--device-vectors"])
+    assert len(F1) == len(F2) and np.allclose(F1, F2, rtol=1e-10, atol=0)
+    x2 = X2[0].numpy()
+    assert np.linalg.norm(x2 - X1[0]) <= 1e-9 * np.linalg.norm(X1[0])
+
+
 def test_kdyn_npts24_matches_oracle():
     from oracle.kdyn import KDynOracle
     from spheremanopt_amd import kdyn
