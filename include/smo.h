@@ -119,7 +119,8 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by t
 /* key 0: checkpoint interval actually in use (1 = every snapshot kept);  key 1: KDYN: bytes of the y-side stack kept by the forward
  * solve so that the adjoint skips the z/y passes of every snapshot (0 if not in use); SHB23: how many calls fell back from the
  * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU);  key 2 (KDYN): number of
- * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch);
+ * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch); SHB23:
+ * workgroups that co-operate on one problem (1 = no cluster: batch > 1, fewer than 256 modes, SMO_SHB_CLUSTER=0 or after a time-out);
  * key 3 (KDYN): layout of the y-transformed work fields, 0 = planes [c][kx][y][z], 1 = z-block major [c][z/8][kx][y][z%8]. */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 

@@ -266,7 +266,7 @@ template <int NH> __device__ __forceinline__ void shb_gemv(const double* __restr
 // member still not arrive (a GPU shared with other work), reruns the call with one workgroup per problem (cluster_retry below).
 // ---------------------------------------------------------------------------------------------------------
 struct Cluster {
-    int KC, k, R;                 // members, my index, rows per member
+    int KC, k, R, rows;           // members, my index, rows per member (R = ceil(dimension / KC)), rows of THIS member (the last one may hold fewer)
     const double* Ms;             // LDS: my rows of the operator, row-major [R][N]
     double* buf;                  // global [2][N] gathered vector (by step parity)
     unsigned* cnt;                // global monotonic arrival counter (zeroed before the launch)
@@ -279,7 +279,7 @@ struct Cluster {
 __device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double* y, int N /* operator dimension */, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     double* dst = c.buf + (size_t)(c.step & 1) * N + (size_t)c.k * c.R;
-    for (int row = wave; row < c.R; row += NT / 64) {
+    for (int row = wave; row < c.rows; row += NT / 64) {
         const double* m = c.Ms + (size_t)row * N;
         double a = 0.0;
         for (int j = lane; j < N; j += 64) a += m[j] * x[j];
@@ -318,6 +318,20 @@ __device__ __forceinline__ bool cluster_gemv(Cluster& c, const double* x, double
     return ok;
 }
 
+// member blockIdx.x % KC of the cluster that works on problem blockIdx.x / KC: rows [k R, k R + rows) of the No x No operator `Mrow` go to the
+// LDS behind the work area (`ms`) and stay there for the whole solve.  Any No: R = ceil(No / KC), the last member holds the remainder.
+__device__ __forceinline__ Cluster cluster_join(int KC, int No, const double* __restrict__ Mrow, double* ms, double* cl_buf, unsigned* cl_cnt,
+                                                unsigned* cl_err, size_t prob, int* flag, int tid) {
+    const int k = (int)(blockIdx.x % KC), R = (No + KC - 1) / KC;
+    Cluster cl{KC, k, R, max(0, min(R, No - k * R)), nullptr, cl_buf + prob * 2 * No, cl_cnt + prob, cl_err, 0u, flag};
+    if (KC > 1) {
+        const double* src = Mrow + (size_t)k * R * No;
+        for (int i = tid; i < cl.rows * No; i += NT) ms[i] = src[i];
+        cl.Ms = ms;
+    }
+    return cl;
+}
+
 template <int NH> struct ShbShared {
     DctWork<NH> w;
     double c[2 * NH], g[2 * NH], r[2 * NH], t[2 * NH], W[2 * NH];
@@ -338,12 +352,15 @@ template <int NH> __device__ void load_tables(ShbShared<NH>& s, const cplx* tw_g
 template <> struct ShbShared<0> {
     DctWork<0> w;
     double *c, *g, *r, *t, *W, *part, *red;
-    int flag;                                      // (cluster mode only; never used here)
+    int* flag_lds;                                 // cluster mode: the LDS word that broadcasts the poll result
 };
-inline size_t shb_any_lds(int N) { const int Ne = (N + 1) & ~1; return (size_t)4 * N * sizeof(cplx) + ((size_t)5 * Ne + 2 * NT + NT / 64) * sizeof(double); }
+// bytes of the work area (a multiple of 16): 4 complex and 5 real vectors, the GEMV partial sums, the reduction words, the cluster flag
+__host__ __device__ inline size_t shb_any_lds(int N) { const int Ne = (N + 1) & ~1; return (size_t)4 * N * sizeof(cplx) + ((size_t)5 * Ne + 2 * NT + NT / 64 + 2) * sizeof(double); }
 template <int NH> struct ShbRef {
     using type = ShbShared<NH>&;
     static __device__ __forceinline__ type get(unsigned char* smem, int, const AnyPlan&) { return *reinterpret_cast<ShbShared<NH>*>(smem); }
+    static __device__ __forceinline__ int* flag(ShbShared<NH>& s) { return &s.flag; }
+    static __device__ __forceinline__ double* rows(unsigned char* smem, int) { return reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>)); }
 };
 template <> struct ShbRef<0> {
     using type = ShbShared<0>;
@@ -351,8 +368,11 @@ template <> struct ShbRef<0> {
         cplx* z = reinterpret_cast<cplx*>(smem);
         double* d = reinterpret_cast<double*>(z + (size_t)4 * N);
         const int Ne = (N + 1) & ~1;
-        return ShbShared<0>{DctWork<0>{z, z + N, z + 2 * N, z + 3 * N, N, pl}, d, d + Ne, d + 2 * Ne, d + 3 * Ne, d + 4 * Ne, d + 5 * Ne, d + 5 * Ne + 2 * NT, 0};
+        return ShbShared<0>{DctWork<0>{z, z + N, z + 2 * N, z + 3 * N, N, pl}, d, d + Ne, d + 2 * Ne, d + 3 * Ne, d + 4 * Ne, d + 5 * Ne, d + 5 * Ne + 2 * NT,
+                            reinterpret_cast<int*>(d + 5 * Ne + 2 * NT + NT / 64)};
     }
+    static __device__ __forceinline__ int* flag(ShbShared<0>& s) { return s.flag_lds; }
+    static __device__ __forceinline__ double* rows(unsigned char* smem, int N) { return reinterpret_cast<double*>(smem + shb_any_lds(N)); }
 };
 template <> __device__ __forceinline__ void load_tables<0>(ShbShared<0>& s, const cplx* tw_g, const cplx*, const cplx* tw4_g, const double* W_g, int tid) {
     for (int i = tid; i < s.w.N; i += NT) { s.w.tw[i] = tw_g[i]; s.w.tw4[i] = tw4_g[i]; s.W[i] = W_g[i]; }
@@ -377,13 +397,7 @@ __global__ __launch_bounds__(NT) void shb_forward_kernel(const double* __restric
     const int NS = cnts ? Nc : N;                    // doubles per snapshot
     X += prob * N;
     stack += prob * (size_t)(n_iters + 1) * NS;
-    Cluster cl{KC, (int)(blockIdx.x % KC), Nc / KC, nullptr, cl_buf + prob * 2 * Nc, cl_cnt + prob, cl_err, 0u, &s.flag};
-    if (KC > 1) {                                    // my rows of S stay in LDS for the whole solve
-        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
-        const double* src = Mrow + (size_t)cl.k * cl.R * Nc;
-        for (int i = tid; i < cl.R * Nc; i += NT) ms[i] = src[i];
-        cl.Ms = ms;
-    }
+    Cluster cl = cluster_join(KC, Nc, Mrow, ShbRef<NH>::rows(smem, N), cl_buf, cl_cnt, cl_err, prob, ShbRef<NH>::flag(s), tid);   // my rows of S
     const bool writer = (cl.k == 0);
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     for (int i = tid; i < N; i += NT) s.t[i] = X[i];
@@ -443,13 +457,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_kernel(const double* __restric
     const size_t prob = blockIdx.x / KC;
     stack += prob * (size_t)(n_iters + 1) * N;
     grad += prob * N;
-    Cluster cl{KC, (int)(blockIdx.x % KC), N / KC, nullptr, cl_buf + prob * 2 * N, cl_cnt + prob, cl_err, 0u, &s.flag};
-    if (KC > 1) {                                    // my rows of S^T stay in LDS for the whole solve
-        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
-        const double* src = Mrow + (size_t)cl.k * cl.R * N;
-        for (int i = tid; i < cl.R * N; i += NT) ms[i] = src[i];
-        cl.Ms = ms;
-    }
+    Cluster cl = cluster_join(KC, N, Mrow, ShbRef<NH>::rows(smem, N), cl_buf, cl_cnt, cl_err, prob, ShbRef<NH>::flag(s), tid);    // my rows of S^T
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
     auto tinv_adj = [&](const double* in, double* out) __attribute__((always_inline)) {      // T^-T x = 1/2 s o DCT2(x), s_0 = 1
@@ -495,13 +503,7 @@ __global__ __launch_bounds__(NT) void shb_adjoint_cnts_kernel(const double* __re
     const size_t prob = blockIdx.x / KC;
     stack += prob * (size_t)(n_iters + 1) * Nc;
     grad += prob * N;
-    Cluster cl{KC, (int)(blockIdx.x % KC), Nc / KC, nullptr, cl_buf + prob * 2 * Nc, cl_cnt + prob, cl_err, 0u, &s.flag};
-    if (KC > 1) {
-        double* ms = reinterpret_cast<double*>(smem + sizeof(ShbShared<NH>));
-        const double* src = Mrow + (size_t)cl.k * cl.R * Nc;
-        for (int i = tid; i < cl.R * Nc; i += NT) ms[i] = src[i];
-        cl.Ms = ms;
-    }
+    Cluster cl = cluster_join(KC, Nc, Mrow, ShbRef<NH>::rows(smem, N), cl_buf, cl_cnt, cl_err, prob, ShbRef<NH>::flag(s), tid);
     load_tables(s, tw_g, twN_g, tw4_g, W_g, tid);
     const double inv_dt = 1.0 / dt;
     auto to_grid = [&](const double* coeff, double* out) __attribute__((always_inline)) {      // T^-1 of a coefficient vector that is zero beyond Nc (always inlined: no device calls, see dct2<0>)
@@ -582,6 +584,7 @@ public:
     cplx *d_tw = nullptr, *d_twN = nullptr, *d_tw4 = nullptr;
     int k_fwd = -1, k_adj = -1;
     int KC = 1;                        // cluster size (1 = one workgroup per problem)
+    int cl_rows = 0;                   // operator rows per cluster member
     int spin_log2 = 22;                // a member gives up after 2^spin_log2 polls (SMO_SHB_SPIN_LOG2; tests force the time-out path with 0)
     bool cluster_off = false;          // a gather timed out once: this context stays with one workgroup per problem
     long long cluster_fallbacks = 0;
@@ -618,7 +621,7 @@ public:
         set_error("SHB23 %s: cluster all-gather timed out and the single-workgroup rerun failed too", who);
         return SMO_ERR_HIP;
     }
-    double info(int key) const override { return key == 0 ? 1.0 : (double)cluster_fallbacks; }
+    double info(int key) const override { return key == 0 ? 1.0 : key == 2 ? (double)(cluster_off ? 1 : KC) : (double)cluster_fallbacks; }
     double* d_clbuf = nullptr;
     unsigned *d_clcnt = nullptr, *d_clerr = nullptr;
 
@@ -674,11 +677,20 @@ public:
         SMO_TRY(pool.upload(&d_tw4, t4, stream));
         SMO_TRY(pool.alloc(&d_stack, (size_t)cfg.batch * (cfg.n_iters + 1) * snapshot_doubles));
         SMO_TRY(pool.alloc(&d_out, (size_t)cfg.batch));
-        // latency mode: a single problem is spread over KC = N^2/8192 CUs (64 KB of operator rows per CU); SMO_SHB_CLUSTER=0 disables
+        // latency mode: a single problem is spread over KC CUs, each keeping R = ceil(Nc / KC) rows of the operator in its LDS behind the work
+        // area: about 64 KB of rows where they fit (N = 512: 32 members of 16 rows), fewer where the work area leaves less (N = 1024: 6 rows,
+        // 171 members), never more rows than a whole number of rounds of the 16 waves; any Nc (the last member holds the remainder);
+        // SMO_SHB_CLUSTER=0 disables, SMO_SHB_CLUSTER_ROWS=<R> overrides the row count
         const char* env = getenv("SMO_SHB_CLUSTER");
-        if (!any_len && cfg.batch == 1 && Nc >= 256 && N <= 512 && !(env && atoi(env) == 0)) {    // N = 1024 would not fit the LDS
-            KC = (Nc * Nc + 8191) / 8192;                      // members: at most 64 KB of operator rows each ...
-            while (Nc % KC != 0) ++KC;                         // ... and the same number of rows (Nc = 384: 24 members of 16 rows)
+        if (cfg.batch == 1 && Nc >= 256 && !(env && atoi(env) == 0)) {
+            int lds_max = 0;
+            SMO_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg.device));
+            const size_t work = dispatch([&](auto nh) { return (int)work_lds<decltype(nh)::value>(); });
+            int R = std::max(1, 8192 / Nc);
+            if (const char* e = getenv("SMO_SHB_CLUSTER_ROWS")) R = std::max(1, std::min(Nc, atoi(e)));
+            while (R > 1 && work + (size_t)R * Nc * sizeof(double) > (size_t)lds_max) --R;
+            if (R > NT / 64) R -= R % (NT / 64);
+            if (work + (size_t)R * Nc * sizeof(double) <= (size_t)lds_max) { cl_rows = R; KC = (Nc + R - 1) / R; }
         }
         SMO_TRY(pool.alloc(&d_clbuf, (size_t)cfg.batch * 2 * Nc));
         SMO_TRY(pool.alloc(&d_clcnt, (size_t)cfg.batch + 2));          // arrival counters | error flag | spin cap
@@ -722,7 +734,7 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 auto kern = shb_forward_kernel<H>;
-                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)(Nc / KC) * Nc * sizeof(double) : 0);
+                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)cl_rows * Nc * sizeof(double) : 0);
                 SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                 const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);
                 const size_t lds = kc > 1 ? lds_cl : work_lds<H>();
@@ -750,7 +762,7 @@ public:
             return dispatch([&](auto nh) -> int {
                 constexpr int H = decltype(nh)::value;
                 const int No = cnts ? Nc : N;            // operator dimension
-                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)(No / KC) * No * sizeof(double) : 0);
+                const size_t lds_cl = work_lds<H>() + (KC > 1 ? (size_t)cl_rows * No * sizeof(double) : 0);
                 auto go = [&](auto kern, auto&& fire) -> int {
                     SMO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cl));
                     const int kc = force_kc > 0 ? force_kc : cluster_size(kern, lds_cl);

@@ -234,3 +234,33 @@ def test_cluster_timeout_reruns_with_one_workgroup(monkeypatch, cost, adj):
     assert J2 == J0 and np.array_equal(g2, g0)
     J3 = ctx.forward([X])                                         # the context now stays with one workgroup per problem
     assert J3 == J0 and ctx.get(1) == 1
+
+
+@pytest.mark.parametrize("N,cost,rows", [(1000, 0, None), (1023, 0, None), (1024, 0, None), (333, 1, None), (512, 1, None), (512, 0, "7"), (300, 0, "1")])
+def test_cluster_takes_any_length(monkeypatch, N, cost, rows):
+    """The cluster mode is not tied to the instantiated lengths or to row counts that divide: any N with >= 256 modes (odd and prime-free
+    ones, N = 1024 whose work area leaves room for 6 rows only, the Continuous formulation's Nc = N/2 operator) spreads the operator's rows
+    over ceil(Nc / R) workgroups, the last one holding the remainder.  Every row is still summed by one wave in the same order, so the result
+    equals the single-workgroup kernel's up to the GEMV's summation order."""
+    from oracle import shb23 as osh
+    n = 12
+    adj = "Continuous" if cost else "Discrete"
+    if cost:
+        X = osh.synthetic_ic_cnts(osh.SHB23CntsOracle(N, dt=1e-2, N_ITERS=n), 3, 0.0019)
+    else:
+        X = osh.synthetic_ic(osh.SHB23Oracle(N, dt=1e-2, N_ITERS=n), 42, 0.0019)
+    monkeypatch.setenv("SMO_SHB_CLUSTER", "0")
+    ref = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=cost)
+    assert ref.get(2) == 1
+    J0, g0 = ref.forward([X]), ref.adjoint(None, adj)[0]
+    monkeypatch.delenv("SMO_SHB_CLUSTER")
+    if rows:
+        monkeypatch.setenv("SMO_SHB_CLUSTER_ROWS", rows)
+    ctx = _capi.Context(_capi.SMO_SHB23, N, (-20., 20.), 1e-2, n, -0.1, cost=cost)
+    kc = int(ctx.get(2))
+    assert kc > 1 and (not rows or kc == -(-N // int(rows)))
+    J1, g1 = ctx.forward([X]), ctx.adjoint(None, adj)[0]
+    assert ctx.get(1) == 0 and ctx.get(2) == kc                    # no time-out, still a cluster
+    assert abs(J1 - J0) <= 1e-11 * abs(J0) and rel(g1, g0) < 1e-9
+    snap0, snap1 = ref.snapshot(n), ctx.snapshot(n)
+    assert rel(snap1, snap0) < 1e-10
