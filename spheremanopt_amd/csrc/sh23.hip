@@ -412,6 +412,9 @@ public:
             SMO_SH_CASE(20) SMO_SH_CASE(40) SMO_SH_CASE(80) SMO_SH_CASE(160) SMO_SH_CASE(320) SMO_SH_CASE(640)          // 5 * 2^k
             SMO_SH_CASE(60) SMO_SH_CASE(120) SMO_SH_CASE(240) SMO_SH_CASE(480) SMO_SH_CASE(960)                         // 15 * 2^k
             SMO_SH_CASE(28) SMO_SH_CASE(56) SMO_SH_CASE(112) SMO_SH_CASE(224) SMO_SH_CASE(448) SMO_SH_CASE(896)         // 7 * 2^k
+            SMO_SH_CASE(36) SMO_SH_CASE(72) SMO_SH_CASE(144) SMO_SH_CASE(288) SMO_SH_CASE(576)                          // 9 * 2^k
+            SMO_SH_CASE(50) SMO_SH_CASE(100) SMO_SH_CASE(200) SMO_SH_CASE(400) SMO_SH_CASE(800)                         // 25 * 2^k: the round decimal sizes
+            SMO_SH_CASE(150) SMO_SH_CASE(300) SMO_SH_CASE(600) SMO_SH_CASE(250) SMO_SH_CASE(500) SMO_SH_CASE(1000)      // 75 * 2^k, 125 * 2^k
 #undef SMO_SH_CASE
             case 1024: return f(std::integral_constant<int, 1024>());
         }
