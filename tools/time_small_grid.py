@@ -12,7 +12,7 @@ from spheremanopt_amd import kdyn  # noqa: E402
 from spheremanopt_amd.devvec import DeviceVector, to_device  # noqa: E402
 
 sizes = [int(a) for a in sys.argv[1:]] or [24, 32, 48, 64]
-n = 2000
+n = int(os.environ.get("SMO_TOOL_ITERS", "2000"))
 for N in sizes:
     rec = {"npts": N, "n_iters": n}
     for mode in ("0", "1"):
