@@ -262,6 +262,10 @@ int         smo_timing_enable(smo_ctx* ctx, int on);
 /* time exactly the classes whose bit is set in `class_mask` (bit k = class k; 0 = off); resets the accumulators.  The multi-GPU benchmark
  * times its dominant kernel class AND the "slab_exchange(all-to-all)" class (events around every grouped send/recv, on the stream it runs on). */
 int         smo_timing_select(smo_ctx* ctx, unsigned long long class_mask);
+/* of the selected classes, time every `every`-th launch only (default 1 = all): the averages become those of a uniform sample of the launches,
+ * the event records (two per timed launch, each a marker in the queue that keeps the next kernel from overlapping the previous one's tail)
+ * cost 1/every as much.  Stays in force until changed; smo_timing_get's `launches` counts the TIMED launches. */
+int         smo_timing_stride(smo_ctx* ctx, int every);
 int         smo_timing_classes(const smo_ctx* ctx);
 int         smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms,
                            double* bytes_per_launch);

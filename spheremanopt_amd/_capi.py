@@ -24,7 +24,7 @@ EXPORTS = [
     "smo_snapshot_len", "smo_snapshot_read", "smo_transform", "smo_kdyn_op", "smo_set_stream", "smo_timing_enable", "smo_timing_classes", "smo_timing_get", "smo_timing_hbm_bytes",
     "smo_vec_alloc", "smo_vec_free", "smo_vec_pool_release", "smo_vec_pool_bytes", "smo_vec_upload", "smo_vec_download", "smo_vec_axpby",
     "smo_host_alloc", "smo_host_free",
-    "smo_comm_unique_id", "smo_comm_init", "smo_comm_set_transport", "smo_comm_get", "smo_comm_library", "smo_timing_select",
+    "smo_comm_unique_id", "smo_comm_init", "smo_comm_set_transport", "smo_comm_get", "smo_comm_library", "smo_timing_select", "smo_timing_stride",
 ]
 
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)      # smo_alltoall_fn
@@ -117,6 +117,7 @@ def lib():
     L.smo_comm_get.argtypes = [vp, C.c_int, dp]
     L.smo_comm_library.restype = C.c_char_p
     L.smo_timing_select.argtypes = [vp, C.c_ulonglong]
+    L.smo_timing_stride.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -399,8 +400,10 @@ class Context:
         _check(lib().smo_get(self._h, int(key), C.byref(v)))
         return v.value
 
-    def timing_enable(self, on=True, only=None, select=None):
-        """on=False: off; on=True: every kernel class; only=k: just class k (index into timing()); select=[k, ...]: exactly those classes."""
+    def timing_enable(self, on=True, only=None, select=None, every=1):
+        """on=False: off; on=True: every kernel class; only=k: just class k (index into timing()); select=[k, ...]: exactly those classes;
+        every=n: of those, every n-th launch only (a uniform sample at 1/n of the event overhead)."""
+        _check(lib().smo_timing_stride(self._h, int(every)))
         if select is not None:
             mask = 0
             for k in select:

@@ -234,6 +234,12 @@ int smo_timing_select(smo_ctx* ctx, unsigned long long class_mask) {
     ctx->impl->tm().mask = class_mask;
     return SMO_OK;
 }
+int smo_timing_stride(smo_ctx* ctx, int every) {
+    CHECK_CTX(ctx);
+    if (every < 1) { smo::set_error("smo_timing_stride: every = %d (>= 1 expected)", every); return SMO_ERR_ARG; }
+    ctx->impl->tm().stride = every;
+    return SMO_OK;
+}
 int smo_timing_classes(const smo_ctx* ctx) { return (ctx && ctx->impl) ? (int)ctx->impl->tm().cls.size() : 0; }
 int smo_timing_get(smo_ctx* ctx, int k, const char** name, long long* launches, double* total_ms, double* bytes_per_launch) {
     CHECK_CTX(ctx);

@@ -61,6 +61,7 @@ hipEvent_t Timing::get() {
 void Timing::reset() {
     (void)flush();
     for (auto& c : cls) { c.launches = 0; c.total_ms = 0; }
+    for (auto& n : seen) n = 0;
 }
 void Timing::begin(int k, hipStream_t s) {
     Pending p{k, get(), get()};

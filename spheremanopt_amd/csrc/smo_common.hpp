@@ -88,9 +88,12 @@ class Timing {
 public:
     bool on = false;
     unsigned long long mask = ~0ull;  // classes whose launches are timed (bit k = class k): keeps the event overhead out of the other launches
+    int stride = 1;                   // of a selected class, every stride-th launch is timed (smo_timing_stride): a uniform sample at 1/stride of the event cost
+    std::vector<long long> seen;      // launches of each class since the last reset, timed or not
     std::vector<TimingClass> cls;
     int add_class(const char* name, double bytes, double hbm = -1.0) {
         cls.push_back({name, bytes, 0, 0.0, hbm < 0 ? bytes : hbm});
+        seen.push_back(0);
         return (int)cls.size() - 1;
     }
     void reset();
@@ -109,6 +112,7 @@ struct ScopedTimer {
     Timing& t; int k; hipStream_t s;
     bool active;
     ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && ((t_.mask >> k_) & 1ull)) {
+        if (active && t.stride > 1) active = (t.seen[k]++ % t.stride) == 0;
         if (active) t.begin(k, s);
     }
     ~ScopedTimer() { if (active) t.end(k, s); }

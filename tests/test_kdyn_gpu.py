@@ -507,3 +507,29 @@ def test_device_transform_pair(N):
     o = _oracle(N, 1., 1e-3, 1, "Final")
     assert rel(back, np.stack([o.to_coeff(g_host[i]) for i in range(3)])) < 1e-13
     dom.drop_contexts()
+
+
+def test_timing_stride_samples_the_launches():
+    """smo_timing_stride: of the selected classes every n-th launch carries events; counts and averages are those of the sample."""
+    N, n = 16, 24
+    dom = kdyn.KDynDomain(N)
+    ctx = dom.context(1., 1e-3, n, "Final")
+    B, U = _fields(dom.G, dirty=False)
+    ctx.timing_enable(True)
+    J0 = ctx.forward([B, U]); ctx.adjoint(None)
+    full = {t["kernel"]: t for t in ctx.timing()}
+    ctx.timing_enable(True, every=5)
+    J1 = ctx.forward([B, U]); ctx.adjoint(None)
+    samp = {t["kernel"]: t for t in ctx.timing()}
+    assert J1 == J0
+    for k, t in full.items():
+        assert samp[k]["launches"] == -(-t["launches"] // 5), (k, t["launches"], samp[k]["launches"])
+    x = "kd_x_pass<fused_adj>"
+    assert full[x]["launches"] == n and samp[x]["total_ms"] > 0
+    with pytest.raises(_capi.SmoError):
+        ctx.timing_enable(True, every=0)
+    ctx.timing_enable(False)                                   # back to every launch for whoever enables timing next
+    ctx.timing_enable(True)
+    ctx.forward([B, U])
+    assert {t["kernel"]: t for t in ctx.timing()}["kd_x_pass<fused_fwd>"]["launches"] == n
+    dom.drop_contexts()
