@@ -403,6 +403,8 @@ struct XSpec {
     cplx* outB;
 };
 
+constexpr bool only_2_and_3(int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 0) n /= 3; return n == 1; }
+
 template <int L, int MODE, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
                                        cplx* buf, const TW tw, const size_t i0, const int tid) {
@@ -484,14 +486,26 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                 buf[ix(b, L - kx)] = mk(X1.re + X2.im, X2.re - X1.im);        // conj(X1) + i conj(X2)
             }
         }
+        constexpr int S3 = L / 3;
+        constexpr int ICNT = (HP * S3 + NT - 1) / NT;
+        cplx U0[3][3];                              // velocity at the first item's points, [k][component]
+        // SMO_X_FWD_U_EARLY=1: the velocity is requested before the inverse transform's LDS stages instead of after them
+#ifndef SMO_X_FWD_U_EARLY
+#define SMO_X_FWD_U_EARLY 1
+#endif
+        constexpr bool UEARLY = SMO_X_FWD_U_EARLY && MODE == X_FUSED_FWD;
+        if (UEARLY) {
+            const int j = tid / HP, p = tid - j * HP;
+            if (tid < HP * S3 && line_ok(p))
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    for (int c = 0; c < 3; ++c) U0[k][c] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
+        }
         __syncthreads();
         fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
             return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];        // the zero padding is never stored
         });
-        constexpr int S3 = L / 3;
-        constexpr int ICNT = (HP * S3 + NT - 1) / NT;
         cplx Win[ICNT][NF][3][3];                   // [item][field group][component][k]: inputs of the last inverse stage
-        cplx U0[3][3];                              // velocity at the first item's points, [k][component]
 #pragma unroll
         for (int i = 0; i < ICNT; ++i) {
             const int t = tid + i * NT, j = t / HP, p = t - j * HP;
@@ -500,7 +514,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                 for (int f = 0; f < NF; ++f)
                     for (int c = 0; c < 3; ++c)
                         for (int k = 0; k < 3; ++k) Win[i][f][c][k] = buf[ix((f * 3 + c) * HP + p, j + S3 * k)];
-                if (i == 0)
+                if (i == 0 && !UEARLY)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
                         for (int c = 0; c < 3; ++c) {
@@ -613,14 +627,31 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     const XOrigin xo = x_origin(i0, g);
     auto spec_off = [&](int c, int kx, int p) -> size_t { return xo.base + c * xo.cs + kx * xo.ks + 2 * p; };
 
-    auto stage_in = [&](const cplx* src, auto ntl) {           // spectra of one field group -> Hermitian-extended lines in the tile
+    // SMO_X_SEQ_PREFETCH = n: the first n (of SCNT) spectral items of B_f per thread are requested before the last forward stage of F1 instead
+    // of after F1's store loop: part of one global-memory round trip leaves the tile's critical path.  Registers decide how many: omega's grid
+    // values are live there, unlike in the second half where the running sum is requested at the same place.
+#ifndef SMO_X_SEQ_PREFETCH
+#define SMO_X_SEQ_PREFETCH (!only_2_and_3(L) ? 0 : L > 192 ? 3 : 2)     // lengths with a radix-5 / radix-7 stage have no registers to spare
+#endif
+    constexpr int PRE = (SMO_X_SEQ_PREFETCH) < SCNT ? (SMO_X_SEQ_PREFETCH) : SCNT;
+    cplx pre_in[PRE > 0 ? PRE : 1][2];
+    auto request_in = [&](const cplx* src, auto ntl) {         // the first PRE loads of stage_in, issued early
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int t = tid + i * NT, p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
+            pre_in[i][0] = mk(0, 0); pre_in[i][1] = mk(0, 0);
+            if (t < NITEM && line_ok(p)) { const cplx* q = src + spec_off(c, kx, p); pre_in[i][0] = ld_cplx<decltype(ntl)::value>(q); pre_in[i][1] = ld_cplx<decltype(ntl)::value>(q + 1); }
+        }
+    };
+    auto stage_in = [&](const cplx* src, auto ntl, auto requested, auto&& before_head) {           // spectra of one field group -> Hermitian-extended lines in the tile
 #pragma unroll
         for (int i = 0; i < SCNT; ++i) {
             const int t = tid + i * NT;
             if (t >= NITEM) break;
             const int p = t % HP, r = t / HP, c = r % 3, kx = r / 3;
             cplx X1 = mk(0, 0), X2 = mk(0, 0);
-            if (line_ok(p)) { const cplx* q = src + spec_off(c, kx, p); X1 = ld_cplx<decltype(ntl)::value>(q); X2 = ld_cplx<decltype(ntl)::value>(q + 1); }
+            if (decltype(requested)::value && i < PRE) { X1 = pre_in[i][0]; X2 = pre_in[i][1]; }
+            else if (line_ok(p)) { const cplx* q = src + spec_off(c, kx, p); X1 = ld_cplx<decltype(ntl)::value>(q); X2 = ld_cplx<decltype(ntl)::value>(q + 1); }
             const int b = c * HP + p;
             if (kx == 0) buf[ix(b, 0)] = mk(X1.re, X2.re);
             else {
@@ -628,6 +659,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
                 buf[ix(b, L - kx)] = mk(X1.re + X2.im, X2.re - X1.im);
             }
         }
+        before_head();
         __syncthreads();
         fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
             return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];
@@ -663,8 +695,14 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
 #define SMO_X_SEQ_LATE_SUM 0
 #endif
     cplx old_sum[SMO_X_SEQ_LATE_SUM ? 1 : SCNT][2];
+    // SMO_X_SEQ_REQ_EARLY=1: these requests (B_f's spectra in the first half, the running sum in the second) are issued before the whole forward
+    // tail instead of before its last stage (G = 192: -1.3 %; at G = 384 the longer live ranges spill: +18 %)
+#ifndef SMO_X_SEQ_REQ_EARLY
+#define SMO_X_SEQ_REQ_EARLY (only_2_and_3(L) && L <= 192)
+#endif
     auto forward_and_store = [&](cplx* dst, const bool acc) {
-        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
+        auto requests = [&]() {
+            if (!acc && PRE > 0) request_in(sp.inB, std::integral_constant<bool, (SMO_X_NT & 2) != 0>());
             if (acc && !SMO_X_SEQ_LATE_SUM) {
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
@@ -675,7 +713,9 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
                     }
                 }
             }
-        });
+        };
+        if (SMO_X_SEQ_REQ_EARLY) requests();
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() { if (!SMO_X_SEQ_REQ_EARLY) requests(); });
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < SCNT; ++i) {
@@ -701,16 +741,24 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
 
     // ---- omega: spectrum -> grid, kept in registers -------------------------------------------------------------------------
     cplx Wom[ICNT][3][3], Wy[ICNT][3][3];
-    stage_in(sp.inA, std::integral_constant<bool, (SMO_X_NT & 32) != 0>());      // omega's spectrum is dead once read
+    // SMO_X_SEQ_U_EARLY=1: the velocity is requested before omega's inverse transform (in flight during its LDS stages; omega's grid values are
+    // not live yet) instead of after it
+#ifndef SMO_X_SEQ_U_EARLY
+#define SMO_X_SEQ_U_EARLY only_2_and_3(L)
+#endif
+    auto request_U = [&]() {
+#pragma unroll
+        for (int i = 0; i < ICNT; ++i) {
+            const int t = tid + i * NT, j = t / HP, p = t - j * HP;
+            if (t < HP * S3 && line_ok(p))
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) Wy[i][c][k] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
+        }
+    };
+    stage_in(sp.inA, std::integral_constant<bool, (SMO_X_NT & 32) != 0>(), std::false_type(), [&]() { if (SMO_X_SEQ_U_EARLY) request_U(); });      // omega's spectrum is dead once read
     read_win(Wom);
-#pragma unroll
-    for (int i = 0; i < ICNT; ++i) {                            // the velocity is requested before the barrier: in flight while the others read
-        const int t = tid + i * NT, j = t / HP, p = t - j * HP;
-        if (t < HP * S3 && line_ok(p))
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                for (int k = 0; k < 3; ++k) Wy[i][c][k] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
-    }
+    if (!SMO_X_SEQ_U_EARLY) request_U();                        // requested before the barrier: in flight while the others read
     __syncthreads();
     // ---- F1 = omega x U -> forward -> out A --------------------------------------------------------------------------------
 #pragma unroll
@@ -725,7 +773,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     forward_and_store(sp.outA, false);
     __syncthreads();
     // ---- B_f: spectrum -> grid; F2' = omega x B_f -> forward -> running sum (out B) -----------------------------------------------
-    stage_in(sp.inB, std::integral_constant<bool, (SMO_X_NT & 2) != 0>());
+    stage_in(sp.inB, std::integral_constant<bool, (SMO_X_NT & 2) != 0>(), std::integral_constant<bool, (PRE > 0)>(), []() {});
     read_win(Wy);
     __syncthreads();
 #pragma unroll
@@ -772,7 +820,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FU
     __shared__ cplx tw_s[NTW];
     const int tid = threadIdx.x;
     for (int i = tid; i < NTW; i += NT) tw_s[i] = tw_g[i];
-    __syncthreads();
+    // SMO_X_TW_NOSYNC=1: no barrier here — the fused tiles stage their spectra into the tile buffer first and put a barrier behind that loop
+    // before the first butterfly reads a twiddle, so the table's loads and the spectra's are in flight together
+#ifndef SMO_X_TW_NOSYNC
+#define SMO_X_TW_NOSYNC 1
+#endif
+    if (!(SMO_X_TW_NOSYNC && (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ || MODE == X_FUSED_ADJ_SEQ))) __syncthreads();
     size_t tile = blockIdx.x;
     if (PAIRED > 1 && blockIdx.x < (gridDim.x / (8 * PAIRED)) * (8 * PAIRED)) {
         const unsigned q = blockIdx.x / (8 * PAIRED), r = blockIdx.x % (8 * PAIRED);

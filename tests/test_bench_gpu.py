@@ -37,8 +37,8 @@ def test_kdyn_line_contract():
     # frac is taken against the compulsory bytes of the fused kernel: a fraction of the peak, never above it; the unfused count rides along
     assert 0 < r["frac"] <= 1.0 and r["achieved_algorithmic"] >= r["achieved"]
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    # the dominant class carries HIP events on every 8th of its launches inside the timed region (20 launches per gradient here, 2 steps)
-    assert r["timing_stride"] == 8 and r["launches_timed"] == (2 * 20) // 8
+    # the dominant class carries HIP events on every 8th of its launches inside the timed region (a uniform sample)
+    assert r["timing_stride"] == 8 and 1 <= r["launches_timed"] <= (2 * 2 * 22 + 7) // 8      # a class is launched at most ~2x per time step
     # no PMC summary of a 32^3 run is committed: traffic must be null with the reason, not a number from another build / size
     assert r["traffic"] is None and "reason" in r["traffic_source"]
     # `value` is SURVEY 8d's metric: the timed steps hand over HOST vectors (H2D of X and D2H of grad J inside the timed region); the
