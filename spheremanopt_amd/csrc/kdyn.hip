@@ -1171,8 +1171,17 @@ public:
     // (<= 37-49 KB => 3-4 workgroups per CU) and the butterflies per thread stay what they are at G = 192.
     template <int L> struct Shape {
         static constexpr int H = (L > 192) ? 2 : 1;
-        static constexpr int ZNBT = 2 / H, ZNT = 256;          // z passes: row triples per workgroup (6 / 3 FFTs: 18 KB of LDS => 8 workgroups per CU)
-        static constexpr int YZT = SMO_Y_ZT, YNT = 256;          // y pass: z columns per workgroup
+        // z passes: ONE row triple per workgroup (3 FFTs).  G <= 192: 192 threads — every butterfly stage of 192 = 4*4*4*3 is then exactly one round
+        // (144 radix-4 / 192 radix-3 butterflies; with two row triples on 256 threads every stage took two rounds, the second 12-50 % full):
+        // update kernels 49.7-50.2 / 49.0-49.3 -> 48.7 / 47.0-47.5 us at 128^3.  G > 192: 256 threads (192 / 320 / 384 are 5-8 % slower there).
+#ifndef SMO_Z_NBT
+#define SMO_Z_NBT 1
+#endif
+#ifndef SMO_Z_THREADS
+#define SMO_Z_THREADS (L > 192 ? 256 : 192)
+#endif
+        static constexpr int ZNBT = SMO_Z_NBT, ZNT = SMO_Z_THREADS;
+        static constexpr int YZT = SMO_Y_ZT, YNT = 256;          // y pass: z columns per workgroup (512 threads: no change)
         // forward x pass: (y,z) points per workgroup (12 / 6 FFTs; 128-B runs at G = 192).  256 threads: one middle-section item per thread
         // (HP * G/3 = 256), 102-105 VGPRs => 4 waves per SIMD = 16 per CU (192 threads: 148-154 VGPRs, 12 per CU): -5..-7 % on this kernel
         static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
