@@ -20,9 +20,11 @@ namespace smo {
 #ifndef SMO_FFT_MAX_RADIX
 #define SMO_FFT_MAX_RADIX 4
 #endif
-constexpr __host__ __device__ int radix_of(int n) {      // 5 and 7 before 3: a length with a factor 3 (every 3/2-dealiased grid) ends on radix 3
-    return (SMO_FFT_MAX_RADIX >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : ((n % 5 == 0) ? 5 : ((n % 7 == 0) ? 7 : 3))));
+// (MAXR: the policy of one kernel — the template parameter the in-place stages below carry; the library default is SMO_FFT_MAX_RADIX)
+template <int MAXR> constexpr __host__ __device__ int radix_of_r(int n) {      // 5 and 7 before 3: a length with a factor 3 (every 3/2-dealiased grid) ends on radix 3
+    return (MAXR >= 8 && n % 8 == 0) ? 8 : ((n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 : ((n % 5 == 0) ? 5 : ((n % 7 == 0) ? 7 : 3))));
 }
+constexpr __host__ __device__ int radix_of(int n) { return radix_of_r<SMO_FFT_MAX_RADIX>(n); }
 constexpr __host__ __device__ int stage_count(int n) { return n == 1 ? 0 : 1 + stage_count(n / radix_of(n)); }
 constexpr bool fft_length_ok(int n) {
     while (n % 4 == 0) n /= 4;
@@ -199,9 +201,9 @@ struct HalfTwiddles {
     }
 };
 
-template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class TW, class Load, class Store>
-__device__ __forceinline__ void inplace_stage(int tid, TW tw, Load ld, Store st) {
-    constexpr int R = radix_of(N);
+template <int MAXR, int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class TW, class Load, class Store>
+__device__ __forceinline__ void inplace_stage_r(int tid, TW tw, Load ld, Store st) {
+    constexpr int R = radix_of_r<MAXR>(N);
     constexpr int M = N / R;
     constexpr int PER = L / R;
     constexpr int TOTAL = NB * PER;
@@ -238,6 +240,11 @@ __device__ __forceinline__ void inplace_stage(int tid, TW tw, Load ld, Store st)
     }
 }
 
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool PRE_BARRIER, class TW, class Load, class Store>
+__device__ __forceinline__ void inplace_stage(int tid, TW tw, Load ld, Store st) {
+    inplace_stage_r<SMO_FFT_MAX_RADIX, L, N, S, INV, NB, NT, BFAST, PRE_BARRIER>(tid, tw, ld, st);
+}
+
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 
 // Where element (transform b, position pos) of a tile lives in the LDS buffer.
@@ -254,18 +261,18 @@ template <int NB> struct PosMajor {
     __device__ __forceinline__ int operator()(int b, int pos) const { return pos * NB + b; }
 };
 
-template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS> struct InplaceTail {
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, bool LAST_LDS, int MAXR = SMO_FFT_MAX_RADIX> struct InplaceTail {
     template <class IX, class TW, class StoreN, class PreLast>
     static __device__ __forceinline__ void run_ix(cplx* buf, IX ix, int tid, TW tw, StoreN stN, PreLast pre) {
-        constexpr int R = radix_of(N);
+        constexpr int R = radix_of_r<MAXR>(N);
         auto ldL = [&](int b, int pos) { return buf[ix(b, pos)]; };
         if constexpr (N / R == 1) {
             pre();
-            inplace_stage<L, N, S, INV, NB, NT, BFAST, LAST_LDS>(tid, tw, ldL, stN);
+            inplace_stage_r<MAXR, L, N, S, INV, NB, NT, BFAST, LAST_LDS>(tid, tw, ldL, stN);
         } else {
-            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
+            inplace_stage_r<MAXR, L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
             __syncthreads();
-            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS>::run_ix(buf, ix, tid, tw, stN, pre);
+            InplaceTail<L, N / R, S * R, INV, NB, NT, BFAST, LAST_LDS, MAXR>::run_ix(buf, ix, tid, tw, stN, pre);
         }
     }
     template <class TW, class StoreN, class PreLast>
@@ -291,27 +298,32 @@ __device__ __forceinline__ void fft_inplace(cplx* buf, int LD, TW tw, int tid, L
 
 // All stages but the last one (LDS -> LDS, a barrier after each): for callers that fuse their own work into the last stage, whose
 // butterfly j reads and writes the same positions j + (L/R) k — thread-local, so it needs no barrier before what follows on those values.
-template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST> struct InplaceHead {
+template <int L, int N, int S, bool INV, int NB, int NT, bool BFAST, int MAXR = SMO_FFT_MAX_RADIX> struct InplaceHead {
     template <class IX, class TW>
     static __device__ __forceinline__ void run(cplx* buf, IX ix, int tid, TW tw) {
-        constexpr int R = radix_of(N);
+        constexpr int R = radix_of_r<MAXR>(N);
         if constexpr (N / R > 1) {
             auto ldL = [&](int b, int pos) { return buf[ix(b, pos)]; };
-            inplace_stage<L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
+            inplace_stage_r<MAXR, L, N, S, INV, NB, NT, BFAST, true>(tid, tw, ldL, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
             __syncthreads();
-            InplaceHead<L, N / R, S * R, INV, NB, NT, BFAST>::run(buf, ix, tid, tw);
+            InplaceHead<L, N / R, S * R, INV, NB, NT, BFAST, MAXR>::run(buf, ix, tid, tw);
         }
     }
 };
-template <int L> constexpr int last_radix() { int n = L; while (n / radix_of(n) > 1) n /= radix_of(n); return n; }
+template <int L, int MAXR = SMO_FFT_MAX_RADIX> constexpr int last_radix() { int n = L; while (n / radix_of_r<MAXR>(n) > 1) n /= radix_of_r<MAXR>(n); return n; }
 
+// (MAXR first: the radix policy of the calling kernel)
+template <int MAXR, int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, class IX, class TW, class Load0>
+__device__ __forceinline__ void fft_inplace_head_r(cplx* buf, IX ix, TW tw, int tid, Load0 ld0) {
+    constexpr int R0 = radix_of_r<MAXR>(L);
+    static_assert(L / R0 > 1, "transform needs at least two stages");
+    inplace_stage_r<MAXR, L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
+    __syncthreads();
+    InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST, MAXR>::run(buf, ix, tid, tw);
+}
 template <int L, bool INV, int NB, int NT, bool BFAST, bool FIRST_LDS, class IX, class TW, class Load0>
 __device__ __forceinline__ void fft_inplace_head(cplx* buf, IX ix, TW tw, int tid, Load0 ld0) {
-    constexpr int R0 = radix_of(L);
-    static_assert(L / R0 > 1, "transform needs at least two stages");
-    inplace_stage<L, L, 1, INV, NB, NT, BFAST, FIRST_LDS>(tid, tw, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
-    __syncthreads();
-    InplaceHead<L, L / R0, R0, INV, NB, NT, BFAST>::run(buf, ix, tid, tw);
+    fft_inplace_head_r<SMO_FFT_MAX_RADIX, L, INV, NB, NT, BFAST, FIRST_LDS>(buf, ix, tw, tid, ld0);
 }
 
 

@@ -404,6 +404,15 @@ struct XSpec {
 };
 
 constexpr bool only_2_and_3(int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 0) n /= 3; return n == 1; }
+// Radix policy of the adjoint x passes (both forms: the same arithmetic per element, bit-identical results): butterflies up to radix 8 where the
+// registers of the sequential form allow it — in the inverse heads at G <= 192 (165 VGPRs, -2.3 %), in the forward tails at G = 288, 384 (168,
+// -1.5 %); the other combination spills at either size (17-50 registers); lengths with a radix-5 / radix-7 stage stay with radix 4
+#ifndef SMO_X_SEQ_HEAD_RADIX
+#define SMO_X_SEQ_HEAD_RADIX ((only_2_and_3(L) && L <= 192) ? 8 : SMO_FFT_MAX_RADIX)
+#endif
+#ifndef SMO_X_SEQ_TAIL_RADIX
+#define SMO_X_SEQ_TAIL_RADIX ((only_2_and_3(L) && L > 192) ? 8 : SMO_FFT_MAX_RADIX)
+#endif
 
 template <int L, int MODE, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
@@ -467,7 +476,15 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         // butterflies -> cross product(s) at its three grid points -> first forward butterflies (+ twiddles), touching the LDS once
         // (read j + k a, write 3 j + k) with one barrier in between, instead of three round trips and three barriers.  The velocity is
         // requested before that barrier and arrives while the others finish reading.  Item = (j, p), p fastest.
-        static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
+        // Radix policy of the fused FORWARD pass: butterflies up to radix 8 (192 = 8*8*3, 384 = 8*8*2*3: one LDS round trip and one barrier less per
+        // direction; 117-120 VGPRs, still four waves per SIMD): -3 % at G = 192, -5 % at G = 384.  The adjoint passes (no registers to spare) and the
+        // z / y passes get slower with it and keep radix 4.
+#ifndef SMO_X_FWD_RADIX
+#define SMO_X_FWD_RADIX 8
+#endif
+        constexpr int XRH = (MODE == X_FUSED_FWD) ? SMO_X_FWD_RADIX : (MODE == X_FUSED_ADJ ? SMO_X_SEQ_HEAD_RADIX : SMO_FFT_MAX_RADIX);      // inverse head
+        constexpr int XRT = (MODE == X_FUSED_FWD) ? SMO_X_FWD_RADIX : (MODE == X_FUSED_ADJ ? SMO_X_SEQ_TAIL_RADIX : SMO_FFT_MAX_RADIX);      // forward tail
+        static_assert(last_radix<L, XRH>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
         // every stored mode feeds two positions of the Hermitian-extended line (kx and G - kx): read it once, coalesced (p fastest: one
         // 128-byte run per (component, kx)), and write both into the tile; the first butterfly stage then works LDS -> LDS
         for (int t = tid; t < (L / 3) * NF * 3 * HP; t += NT) {
@@ -502,7 +519,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
                     for (int c = 0; c < 3; ++c) U0[k][c] = ld_pair<(SMO_X_NT & 1) != 0>(gridU + u_off(c, j + S3 * k, i0 + 2 * p, g));
         }
         __syncthreads();
-        fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
+        fft_inplace_head_r<XRH, L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
             return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];        // the zero padding is never stored
         });
         cplx Win[ICNT][NF][3][3];                   // [item][field group][component][k]: inputs of the last inverse stage
@@ -569,7 +586,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
         __syncthreads();
         // remaining forward stages (sub-length a, stride 3); group B of the adjoint pass is a running sum: its old values are requested
         // before the last stage
-        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true, XRT>::run_ix(buf, ix, tid, tw, st_buf, [&]() {
             if (ACC) {
 #pragma unroll
                 for (int i = 0; i < SCNT; ++i) {
@@ -619,7 +636,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     constexpr int NITEM = S3 * 3 * HP;                         // stored modes of one field group = items of the staging / split loops
     constexpr int SCNT = (NITEM + NT - 1) / NT;
     constexpr int ICNT = (HP * S3 + NT - 1) / NT;              // middle-section items (j, p) per thread
-    static_assert(last_radix<L>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
+    static_assert(last_radix<L, SMO_X_SEQ_HEAD_RADIX>() == 3, "G = 3N/2: the last Stockham stage is radix 3");
     const size_t plane = (size_t)g.G * g.Gzl;
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
     auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
@@ -661,7 +678,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
         }
         before_head();
         __syncthreads();
-        fft_inplace_head<L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
+        fft_inplace_head_r<SMO_X_SEQ_HEAD_RADIX, L, true, NB, NT, true, true>(buf, ix, tw, tid, [&](int b, int pos) -> cplx {
             return (pos >= L / 3 && pos <= L - L / 3) ? mk(0, 0) : buf[ix(b, pos)];
         });
     };
@@ -715,7 +732,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
             }
         };
         if (SMO_X_SEQ_REQ_EARLY) requests();
-        InplaceTail<L, L / 3, 3, false, NB, NT, true, true>::run_ix(buf, ix, tid, tw, st_buf, [&]() { if (!SMO_X_SEQ_REQ_EARLY) requests(); });
+        InplaceTail<L, L / 3, 3, false, NB, NT, true, true, SMO_X_SEQ_TAIL_RADIX>::run_ix(buf, ix, tid, tw, st_buf, [&]() { if (!SMO_X_SEQ_REQ_EARLY) requests(); });
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < SCNT; ++i) {
