@@ -236,7 +236,7 @@ def test_cluster_timeout_reruns_with_one_workgroup(monkeypatch, cost, adj):
     assert J3 == J0 and ctx.get(1) == 1
 
 
-@pytest.mark.parametrize("N,cost,rows", [(1000, 0, None), (1023, 0, None), (1024, 0, None), (333, 1, None), (512, 1, None), (512, 0, "7"), (300, 0, "1")])
+@pytest.mark.parametrize("N,cost,rows", [(1000, 0, None), (1023, 0, None), (1024, 0, None), (257, 0, None), (333, 1, None), (301, 1, None), (512, 1, None), (512, 0, "7"), (300, 0, "1")])
 def test_cluster_takes_any_length(monkeypatch, N, cost, rows):
     """The cluster mode is not tied to the instantiated lengths or to row counts that divide: any N with >= 256 modes (odd and prime-free
     ones, N = 1024 whose work area leaves room for 6 rows only, the Continuous formulation's Nc = N/2 operator) spreads the operator's rows
