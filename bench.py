@@ -4,7 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sh23|kdyn|shb23] [--no-cpu-baseline]
 
 One "step" = one gradient evaluation = one forward solve (J) + one adjoint solve (grad J) at the same X over the
-full time window, inputs already resident in HBM.  Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
+full time window.  On one GPU the timed steps hand over HOST vectors (H2D of X and D2H of grad J inside the timed
+region); the device-resident rate rides along as config.value_device_vectors.  Prints ONE JSON line (rank 0).  See DESIGN.md
+"Measurement".
 """
 import argparse
 import json
@@ -232,17 +234,87 @@ def bench_pois(a, torch, rank, world):
     return steps, warm, el, 1, roof, cfg, None
 
 
-def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=4):
-    """Oracle timed on a bounded sample: `sample_steps` forward + adjoint steps at the full grid, scaled to n_iters."""
-    from oracle.kdyn import KDynOracle
-    o = KDynOracle(N, Rm=Rm, dt=dt, N_ITERS=sample_steps, workers=workers)
-    t0 = time.perf_counter()
-    o.forward([B, U]); o.adjoint([B, U])
-    el = time.perf_counter() - t0
+def cpu_topology():
+    """What the all-core CPU leg may use: the physical cores of ONE socket (socket of the first CPU this process may run on), cut down to
+    the process' affinity mask and to the cgroup's CPU quota.  Returns a dict with the model name, sockets, physical cores per socket, the
+    CPUs chosen (one hardware thread per physical core) and the limits that applied."""
+    info = {"model": None, "sockets": None, "physical_cores_per_socket": None, "affinity_cpus": None, "cgroup_cpu_quota": None}
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                info["model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    info["affinity_cpus"] = len(allowed)
+    topo = {}
+    for c in range(os.cpu_count() or 1):
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            topo[c] = (int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except (OSError, ValueError):
+            pass
+    chosen = allowed
+    if topo:
+        socks = sorted({v[0] for v in topo.values()})
+        info["sockets"] = len(socks)
+        info["physical_cores_per_socket"] = len({v[1] for v in topo.values() if v[0] == socks[0]})
+        s0 = topo.get(allowed[0], (socks[0], 0))[0]
+        seen, chosen = set(), []
+        for c in allowed:
+            if c in topo and topo[c][0] == s0 and topo[c][1] not in seen:
+                seen.add(topo[c][1]); chosen.append(c)
+        info["socket_used"] = s0
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                quota = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                q = float(t[0]); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = None if q <= 0 else q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_cpu_quota"] = quota
+    if quota is not None and quota >= 1 and len(chosen) > int(quota):
+        chosen = chosen[:int(quota)]
+    info["cpus_used"] = chosen
+    return info
+
+
+def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=4, cpus=None):
+    """Oracle timed on a bounded sample: `sample_steps` forward + adjoint steps at the full grid, scaled to n_iters.  The restatement with
+    its pointwise stages threaded (oracle.kdyn.ThreadedKDynOracle: same arithmetic, bit-identical gradients); `cpus`: pin this leg to
+    those CPUs (one socket's physical cores) for its duration."""
+    from oracle.kdyn import ThreadedKDynOracle
+    old = None
+    if cpus and hasattr(os, "sched_setaffinity"):
+        try:
+            old = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, cpus)          # threads started from here on (the pool's, pocketfft's) inherit the mask
+        except OSError:
+            old = None
+    try:
+        o = ThreadedKDynOracle(N, Rm=Rm, dt=dt, N_ITERS=sample_steps, threads=workers)
+        t0 = time.perf_counter()
+        o.forward([B, U]); o.adjoint([B, U])
+        el = time.perf_counter() - t0
+        if o.pool is not None:
+            o.pool.shutdown()
+    finally:
+        if old is not None:
+            os.sched_setaffinity(0, old)
     per_step = el / sample_steps          # includes the one-off transforms of X and the final gradient transforms
     return {"value": 1.0 / (per_step * n_iters), "unit": "gradient evals/s", "cores": workers, "kind": "port",
             "sample": "%d of %d forward+adjoint time steps at the full %d^3 grid (NumPy/pocketfft restatement of the Dedalus "
-                      "path, %d thread(s)), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers, el)}
+                      "path, %d thread(s)%s), %.1f s, extrapolated linearly" % (sample_steps, n_iters, N, workers,
+                      ", pinned to one socket's physical cores" if cpus else "", el)}
 
 
 class _PyLoop:
@@ -448,6 +520,7 @@ def bench_kdyn(a, torch, rank, world):
     # dominant kernel = the byte-moving class with the largest share (the misc class — setup, reductions — has no byte model)
     dom_i = max(range(len(tim)), key=lambda i: tim[i]["total_ms"] if tim[i]["hbm_bytes_per_launch"] > 0 else -1.0)
     share = tim[dom_i]["total_ms"] / tot_ms
+    every_ms = tim[dom_i]["total_ms"] / max(tim[dom_i]["launches"], 1)      # warm-up gradient(s): HIP events around EVERY launch of every class
     # THE TIMED REGION.  SURVEY 8d's metric: one f + one Grad_f at the same X "including H2D of X and D2H of grad J" — the callbacks
     # the reference's optimiser calls hand over host vectors.  On one GPU the timed steps therefore go through the host-buffer entry
     # points (smo_forward / smo_adjoint on pinned vectors); the device-resident rate (vectors already in HBM: what devvec.DeviceVector
@@ -489,6 +562,13 @@ def bench_kdyn(a, torch, rank, world):
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": rate(dom_k["hbm_bytes_per_launch"], avg_ms),
             "peak": 8000.0, "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms, "launches_timed": dom_k["launches"],
             "timing_stride": TIMING_STRIDE, "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
+            # two views of the same kernel's launch time: the sample taken INSIDE the timed region (what `achieved` / `frac` use) and the
+            # warm-up gradient's every-launch average (events around all classes: every kernel runs fenced, at ~9 % more wall time)
+            "avg_launch_ms_sampled": avg_ms, "avg_launch_ms_every_launch": every_ms,
+            "frac_basis": "avg_launch_ms_sampled: every %d-th launch of the dominant class inside the timed region, each with a marker event "
+                          "ahead of its start event (SMO_TIMING_PRE_MARKER) so that the interval does not include the unfenced predecessor's tail"
+                          % TIMING_STRIDE,
+            "frac_every_launch": rate(dom_k["hbm_bytes_per_launch"], every_ms) / 8000.0,
             "achieved_algorithmic": rate(dom_k["bytes_per_launch"], avg_ms), "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             "kernel_time_share": share,
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1),
@@ -547,11 +627,40 @@ def bench_kdyn(a, torch, rank, world):
             cfg["J_matches_oracle_1e-6"] = bool(abs(J - Jo) <= 1e-6 * abs(Jo))
         except Exception:
             pass
+    # Inner_Prod_3 (2 x vector bytes per call; the optimiser calls it ~30x per iteration): HIP events on every launch of a short
+    # series of device-resident calls, and the wall time of a call (kernel + the D2H of the 1024 partial sums + the host reduction)
+    try:
+        dot_i = [i for i, t in enumerate(tim) if t["kernel"].startswith("kd_dot")][0]
+        ctx.timing_enable(only=dot_i)
+        nd = 20
+        ctx.inner_dev(Bd, gB)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nd):
+            ip = ctx.inner_dev(Bd, gB)
+        wall_ms = 1e3 * (time.perf_counter() - t1) / nd
+        dk = ctx.timing()[dot_i]
+        dms = dk["total_ms"] / max(dk["launches"], 1)
+        roof["inner_product"] = {"kernel": dk["kernel"], "bytes_per_call": dk["hbm_bytes_per_launch"], "avg_launch_ms": dms, "launches_timed": dk["launches"],
+                                 "GBps": rate(dk["hbm_bytes_per_launch"], dms), "frac": rate(dk["hbm_bytes_per_launch"], dms) / 8000.0,
+                                 "wall_ms_per_call": wall_ms, "value": ip,
+                                 "note": "smo_inner_dev (Inner_Prod_3, FWD_Solve_KDyn.py:173-181) on device-resident vectors: reads both vectors once"}
+        ctx.timing_enable(False)
+    except Exception as e:                               # never lose the main line because of the extra
+        roof["inner_product"] = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         ss = getattr(a, "cpu_sample_steps", None) or 4
-        cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1, sample_steps=ss)
-        cfg["cpu_all_cores"] = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, os.cpu_count() or 1, sample_steps=ss)
+        topo = cpu_topology()
+        cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1, sample_steps=ss, cpus=topo["cpus_used"][:1])
+        # the all-core leg: ONE socket's physical cores (what north_star's "single-socket CPU baseline" names), never the whole box's threads
+        nthr = max(1, len(topo["cpus_used"]))
+        allc = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, nthr, sample_steps=ss, cpus=topo["cpus_used"])
+        allc["cpu"] = {k: topo[k] for k in ("model", "sockets", "physical_cores_per_socket", "affinity_cpus", "cgroup_cpu_quota")}
+        allc["cores"] = nthr
+        allc["scaling_over_1_core"] = allc["value"] / cpu["value"]
+        cfg["cpu_all_cores"] = allc
+        cfg["cpu_single_socket"] = allc
     return steps, warm, el, 1, roof, cfg, cpu
 
 
@@ -583,14 +692,42 @@ def bench_kdyn_multi(a, torch, devices):
     dom_k = t2[dom_i]
     avg_ms = dom_k["total_ms"] / max(dom_k["launches"], 1)
     ex = [t2[i] for i in ex_i]
+    pull = {2.0: "one gather kernel per exchange reading every peer's send buffer (peer access)", 1.0: "hipMemcpyPeerAsync, one call per peer"}.get(ctx.comm_get(3), "?")
+    rendezvous = ctx.comm_get(4)
+    # What the HOST costs per step pair with this many workers: the same loop at a grid whose kernels take microseconds (same launches, events and
+    # spin-barrier rendezvous per step pair as at the bench grid; the GPU is never the bottleneck there), so its wall time per step pair is the
+    # time the slowest worker needs to ISSUE a step pair — to be set against the kernels' time per step pair of the real grid.
+    host_issue = None
+    try:
+        Nh = 32 if (16 % len(devices) == 0 and (48 // len(devices)) % 2 == 0) else None
+        if Nh:
+            hi = 200
+            hctx = _capi.MultiContext(Nh, (0., 2. * np.pi), dt, hi, Rm, devices, cost="Final", ckpt=1)
+            Gh = 3 * Nh // 2
+            hx = [_capi.pinned_copy(kdyn.synthetic_field(Gh, 1)), _capi.pinned_copy(kdyn.synthetic_field(Gh, 2))]
+            hg = [_capi.pinned_empty(hx[0].size), _capi.pinned_empty(hx[0].size)]
+            hctx.forward(hx); hctx.adjoint(None, out=hg)
+            r0 = hctx.comm_get(4)
+            th = time.perf_counter()
+            for _ in range(3):
+                hctx.forward(hx); hctx.adjoint(None, out=hg)
+            host_issue = {"ms_per_step_pair": 1e3 * (time.perf_counter() - th) / 3 / hi, "grid": "%d^3" % Nh, "n_iters": hi, "workers": len(devices),
+                          "chunks": int(hctx.comm_get(0)), "rendezvous_per_step_pair": (hctx.comm_get(4) - r0) / 3 / hi,
+                          "note": "wall time per step pair of the same multi-device loop at a grid whose kernels take microseconds: launches, event "
+                                  "records / waits and the two spin-barrier rendezvous per exchange, slowest worker"}
+            hctx.close()
+    except Exception as e:
+        host_issue = {"error": repr(e)}
     roof = {"bound": "hbm", "kernel": dom_k["kernel"], "achieved": dom_k["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "traffic": None, "avg_launch_ms": avg_ms, "per_gpu": True, "bytes_per_launch": dom_k["hbm_bytes_per_launch"],
             "all_kernels": [{"kernel": t["kernel"], "launches": t["launches"], "avg_ms": t["total_ms"] / max(t["launches"], 1)} for t in tim]}
     roof["frac"] = roof["achieved"] / roof["peak"]
     cfg = {"workload": "Kinematic dynamo 3D Fourier %d^3, Rm=%g, T=%g, dt=%g, two-field (U,B) gradient, Final cost, discrete adjoint" % (N, Rm, dt * n_iters, dt),
            "grid": [G, G, G], "n_iters": n_iters, "J": J, "devices": list(devices),
-           "parallelism": "ONE process, slab x%d over devices %s (smo_create_multi: one worker thread per device, transposes = peer pulls "
-                          "with hipMemcpyPeerAsync ordered by HIP events; no RCCL)" % (len(devices), list(devices)),
+           "parallelism": "ONE process, slab x%d over devices %s (smo_create_multi: one persistent worker thread per device, transposes = peer pulls "
+                          "ordered by HIP events — %s; no RCCL)" % (len(devices), list(devices), pull),
+           "transpose_pull": pull, "host_rendezvous_per_step_pair": rendezvous / max(steps + max(warm, 1), 1) / n_iters,
+           "host_issue": host_issue, "host_issue_ms_per_step_pair": (host_issue or {}).get("ms_per_step_pair"),
            "vectors": "host (pinned), the reference's full vectors: scatter of X and gather of grad J inside the timed region",
            "checkpoint_interval": int(ctx.get(0)), "chunks": int(ctx.comm_get(0)),
            "compute_ms_per_step_pair": sum(t["total_ms"] for t in tim if not t["kernel"].startswith("slab_exchange")) / max(warm, 1) / n_iters,
@@ -752,14 +889,18 @@ def main():
                         "checkpoint_interval": cf["checkpoint_interval"], "value_device_vectors": cf.get("value_device_vectors"),
                         # the same roofline accounting as the main line, for the dominant kernel of the G = 384 instantiations
                         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                             "avg_launch_ms", "bytes_per_launch", "achieved_algorithmic",
-                                                             "whole_gradient_GBps", "whole_gradient_frac")}}
+                                                             "avg_launch_ms", "avg_launch_ms_sampled", "avg_launch_ms_every_launch", "frac_every_launch",
+                                                             "launches_timed", "timing_stride", "bytes_per_launch", "achieved_algorithmic",
+                                                             "whole_gradient_GBps", "whole_gradient_frac", "inner_product", "all_kernels")}}
                 if cpu2:
                     c256["cpu_baseline"] = cpu2
                     c256["cpu_all_cores"] = cf.get("cpu_all_cores")
                     c256["speedup_vs_cpu_1_core"] = c256["gradient_evals_per_s"] / cpu2["value"]
                     if cf.get("cpu_all_cores"):
                         c256["speedup_vs_cpu_all_cores"] = c256["gradient_evals_per_s"] / cf["cpu_all_cores"]["value"]
+                        # north_star's sentence as a number: this gradient against the same restatement on one socket's physical cores
+                        # (a reported baseline, never the target)
+                        c256["speedup_vs_cpu_single_socket"] = c256["speedup_vs_cpu_all_cores"]
                 cfg["config_256"] = c256
             except Exception as e:                   # never lose the main line because of the extra
                 cfg["config_256"] = {"error": repr(e)}

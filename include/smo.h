@@ -102,10 +102,15 @@ int         smo_create(const smo_config* cfg, smo_ctx** out);
  *       scatters / gathers the z slabs itself (the allgather of Field_to_Vec, FWD_Solve_KDyn.py:118-123, disappears);
  *   smo_forward_dev / smo_adjoint_dev      take ndev slab pointers per component instead: X[c * ndev + i] = component c's slab
  *       [3][G][G][G/ndev] in the HBM of dev_ids[i];
- * inside, one worker thread per device runs the same in-library time loop as with one process per GPU, and a transpose is every device pulling
- * its blocks from its peers with hipMemcpyPeerAsync (peer access over xGMI), ordered by HIP events — no RCCL, no launcher, nothing for the
- * caller to set up.  The same device may be listed more than once (tests on a one-GPU box).  smo_snapshot_read is not available on such a
- * context, smo_inner_dev is replaced by smo_inner_slabs; smo_timing_* report device 0's kernels. */
+ * inside, one persistent worker thread per device runs the same in-library time loop as with one process per GPU, and a transpose is every
+ * device pulling its blocks out of its peers' send buffers (peer access over xGMI), ordered by HIP events — ONE gather kernel per exchange that
+ * reads all peers at once, or one hipMemcpyPeerAsync per peer (SMO_PEER_COPY=kernel|memcpy; smo_comm_get key 3 reports which is in use:
+ * the kernel between ranks that share a device, the copy calls between distinct devices until the kernel has been verified on a multi-GPU
+ * node) — no RCCL, no launcher, nothing for the caller to set up.  The same device may be listed more than once (tests on a one-GPU box).
+ * Not available on such a context: smo_snapshot_read, smo_set_stream (SMO_ERR_UNSUPPORTED: every rank runs on a private stream of its own
+ * device); smo_inner_dev is replaced by smo_inner_slabs; smo_timing_* report device 0's kernels.  smo_inner with full HOST vectors scatters
+ * both vectors again on every call — an optimiser should keep its vectors distributed (one slab per device, smo_vec_*) and call
+ * smo_inner_slabs (spheremanopt_amd/devvec.py: MultiDeviceVector). */
 int         smo_create_multi(const smo_config* cfg, int ndev, const int* dev_ids, smo_ctx** out);
 void        smo_destroy(smo_ctx* ctx);
 const char* smo_last_error(void);
@@ -205,7 +210,8 @@ int smo_comm_init(smo_ctx* ctx, const void* id128);
 int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn all_to_all, smo_allreduce_fn all_reduce_sum, void* user);
 /* (all three arguments NULL: the null transport — exchanges and reductions do nothing.  For profiling one rank's share of a W-way decomposition
  * on a single GPU through the real in-library loop, tools/prof_slab_geometry.py; the results of such a solve are meaningless.) */
-/* key 0: pipelined z chunks per exchange; 1: field-group exchanges per forward+adjoint step pair; 2: 1 if the transport is RCCL */
+/* key 0: pipelined z chunks per exchange; 1: field-group exchanges per forward+adjoint step pair; 2: 1 if the transport is RCCL;
+ * multi-device contexts: 3: how a transpose pulls (2 = gather kernel, 1 = hipMemcpyPeerAsync calls), 4: host rendezvous passed so far */
 int smo_comm_get(const smo_ctx* ctx, int key, double* value);
 /* File of the librccl this library bound for smo_comm_unique_id / smo_comm_init (dladdr of its ncclGetUniqueId), "" if none can be
  * loaded.  A copy already in the process (PyTorch bundles one) is reused, else the system library is loaded; the environment variable
@@ -250,11 +256,12 @@ enum {
 int smo_kdyn_op(smo_ctx* ctx, int op, int i0, int i1, void* p0, void* p1, double* out);
 
 /* Enqueue all further work of the context on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream) so
- * that collectives issued by the host layer on that stream are ordered with the kernels without host synchronisation. */
+ * that collectives issued by the host layer on that stream are ordered with the kernels without host synchronisation.
+ * SMO_ERR_UNSUPPORTED on a multi-device context (smo_create_multi). */
 int smo_set_stream(smo_ctx* ctx, void* hip_stream);
 
 /* HIP-event timing of the kernels launched by the context (measured on the context's stream).
- * smo_timing_enable(ctx, on) resets the accumulators; on = 0 off, 1 every class, 2 + k only class k (two event records per
+ * smo_timing_enable(ctx, on) resets the accumulators; on = 0 off, 1 every class, 2 + k only class k, k < 64 (two event records per
  * launch cost ~2 us on the GPU, so the benchmark times only the dominant class inside its timed region); smo_timing_get returns, for kernel class `k`
  * (0 <= k < smo_timing_classes), its name, number of launches, total milliseconds and the ALGORITHMIC bytes
  * one launch moves (DESIGN.md section "kernels"), so  achieved GB/s = bytes * launches / ms / 1e6. */

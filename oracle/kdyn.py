@@ -178,3 +178,205 @@ def synthetic_field(G, seed, M0=1.0):
     v = np.stack([np.fft.irfftn(V[i], s=(G, G, G), axes=(0, 1, 2)) for i in range(3)])
     v *= np.sqrt(M0 / np.mean((v * v).sum(0)))
     return v.reshape(-1)
+
+
+class ThreadedKDynOracle(KDynOracle):
+    """The same restatement with its POINTWISE stages threaded over kx / x planes — for bench.py's all-core `cpu_baseline` leg only.
+
+    KDynOracle hands `workers` to pocketfft, but its cross products, curls, projections, time-step algebra and the zero-padding copies are
+    serial NumPy, so on 256 hardware threads it ran 1.4x faster than on one: not a baseline an "x times the CPU" sentence
+    can lean on.  Here every such stage runs chunk by chunk on a thread pool (NumPy ufuncs release the GIL); element for element the same
+    operations, so fields and gradients are bit-identical to KDynOracle's — only the grid mean in J is summed per chunk (differs in the last
+    bits; tests/test_oracle.py).  The reference itself forces OMP_NUM_THREADS=1 (Sphere_Grad_Descent.py:2) and scales over MPI ranks."""
+
+    def __init__(self, *args, threads=1, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        kw["workers"] = int(threads)
+        super().__init__(*args, **kw)
+        self.nt = int(threads)
+        self.pool = ThreadPoolExecutor(self.nt) if self.nt > 1 else None
+
+    def _par(self, f, n):
+        """f(slice) over [0, n) in contiguous chunks, one per thread (a few per thread for balance)."""
+        if self.pool is None or n < 2:
+            f(slice(0, n))
+            return
+        parts = min(n, 2 * self.nt)
+        edges = [n * i // parts for i in range(parts + 1)]
+        list(self.pool.map(f, [slice(edges[i], edges[i + 1]) for i in range(parts) if edges[i + 1] > edges[i]]))
+
+    # -- transforms: pocketfft threads the 1-D passes; the truncation / padding copies are chunked here and results land in caller-owned
+    #    arrays (np.stack / np.concatenate of fresh 450-MB arrays were the largest serial item) ----------------------------------------
+    def to_coeff(self, g, out=None):
+        w, G = self.workers, self.G
+        c = sfft.rfft(g, axis=0, workers=w)[:self.a]
+        c = sfft.fft(c, axis=1, workers=w)
+        t = np.empty((self.a, self.m, G), dtype=complex)
+        self._par(lambda s: t.__setitem__(s, c[s][:, self.sel]), self.a)
+        t = sfft.fft(t, axis=2, workers=w)
+        if out is None:
+            out = np.empty((self.a, self.m, self.m), dtype=complex)
+        sc = float(G) ** 3
+        self._par(lambda s: out.__setitem__(s, t[s][:, :, self.sel] / sc), self.a)
+        return out
+
+    def to_grid(self, c, out=None):
+        G, w = self.G, self.workers
+        p = np.empty((self.a, self.m, G), dtype=complex)
+
+        def pad_z(s):
+            p[s] = 0.
+            p[s][:, :, self.sel] = c[s]
+        self._par(pad_z, self.a)
+        p = sfft.ifft(p, axis=2, workers=w)
+        q = np.empty((self.a, G, G), dtype=complex)
+
+        def pad_y(s):
+            q[s] = 0.
+            q[s][:, self.sel] = p[s]
+        self._par(pad_y, self.a)
+        q = sfft.ifft(q, axis=1, workers=w)
+        r = np.empty((G // 2 + 1, G, G), dtype=complex)
+
+        def pad_x(s):
+            r[s] = 0.
+            hi = min(s.stop, self.a)
+            if hi > s.start:
+                r[s.start:hi] = q[s.start:hi]
+        self._par(pad_x, G // 2 + 1)
+        g = sfft.irfft(r, n=G, axis=0, workers=w)
+        sc = float(G) ** 3
+        if out is None:
+            out = g
+        self._par(lambda s: np.multiply(g[s], sc, out=out[s]), G)
+        return out
+
+    def vec_to_coeff(self, X):
+        G = self.G
+        X = np.asarray(X, dtype=float).reshape(3, G, G, G)
+        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        for i in range(3):
+            self.to_coeff(X[i], out=out[i])
+        return out
+
+    def coeff_to_vec(self, C):
+        return self.grid3(C).reshape(-1)
+
+    def grid3(self, C):
+        G = self.G
+        out = np.empty((3, G, G, G))
+        for i in range(3):
+            self.to_grid(C[i], out=out[i])
+        return out
+
+    def coeff3(self, F):
+        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        for i in range(3):
+            self.to_coeff(F[i], out=out[i])
+        return out
+
+    # -- per-mode algebra, chunked over kx --------------------------------------------------------------------------------------
+    def _over_kx(self, f):
+        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        self._par(lambda s: out.__setitem__((slice(None), s), f(s)), self.a)
+        return out
+
+    def project(self, V):
+        return self._over_kx(lambda s: V[:, s] - self.K[:, s] * ((self.K[:, s] * V[:, s]).sum(0) / self.k2s[s]))
+
+    def curl(self, V):
+        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+
+        def f(s):
+            K, v = self.K[:, s], V[:, s]
+            out[0, s] = 1j * (K[1] * v[2] - K[2] * v[1])
+            out[1, s] = 1j * (K[2] * v[0] - K[0] * v[2])
+            out[2, s] = 1j * (K[0] * v[1] - K[1] * v[0])
+        self._par(f, self.a)
+        return out
+
+    def cross(self, A, B):
+        out = np.empty_like(A)
+
+        def f(s):
+            a, b = A[:, s], B[:, s]
+            out[0, s] = a[1] * b[2] - a[2] * b[1]
+            out[1, s] = a[2] * b[0] - a[0] * b[2]
+            out[2, s] = a[0] * b[1] - a[1] * b[0]
+        self._par(f, A.shape[1])
+        return out
+
+    def cnab_update(self, V0, F):
+        def f(s):
+            K, k2s, v0 = self.K[:, s], self.k2s[s], V0[:, s]
+            r = self.beta[s] * v0 + F[:, s]
+            v1 = (r - K * ((K * r).sum(0) / k2s)) / self.alpha[s] - K * ((K * v0).sum(0) / k2s)
+            z = self.zero[s]
+            v1[:, z] = -v0[:, z]
+            return v1
+        return self._over_kx(f)
+
+    def _energy(self, Bg):
+        parts = []
+        self._par(lambda s: parts.append((s.start, float(np.einsum("cxyz,cxyz->", Bg[:, s], Bg[:, s])))), Bg.shape[1])
+        return sum(v for _, v in sorted(parts)) / float(self.G) ** 3
+
+    def forward(self, X):
+        n_it, dt = self.N_ITERS, self.dt
+        Bh = self.vec_to_coeff(X[0])
+        self.Ug = self.grid3(self.vec_to_coeff(X[1]))
+        self.stack = np.zeros((n_it + 1, 3, self.a, self.m, self.m), dtype=complex)      # step index FIRST here: contiguous snapshots
+        J = 0.
+        for n in range(n_it + 1):
+            self.stack[n] = Bh
+            Bg = self.grid3(Bh)
+            e = self._energy(Bg)
+            if self.cost == "Integrated":
+                J += dt * e
+            elif n == n_it:
+                J = e
+            Nh = self.curl(self.coeff3(self.cross(self.Ug, Bg)))
+            Bh = self.cnab_update(Bh, Nh)
+        return -J
+
+    def adjoint(self, X=None, Adjoint_type="Discrete"):
+        S = self.stack
+        self.stack = np.moveaxis(S, 0, -1)            # a VIEW in the base class's [..., n] indexing: the base sweep below runs unchanged
+        try:
+            return self._adjoint_threaded(Adjoint_type)
+        finally:
+            self.stack = S
+
+    def _adjoint_threaded(self, Adjoint_type):
+        n_it, dt = self.N_ITERS, self.dt
+        S = self.stack
+        if Adjoint_type == "Discrete":
+            scale = (dt * self.alpha) if self.cost == "Final" else self.alpha
+            Gh = self.project(-2. * S[..., n_it]) / scale
+            Gh[:, self.zero] = 0.
+            idx = n_it - 1
+        else:
+            Gh = -2. * S[..., n_it]
+            idx = n_it
+        nu = np.zeros_like(Gh)
+        for _ in range(n_it):
+            Bf_h = S[..., idx]; idx -= 1
+            Bf = self.grid3(Bf_h)
+            om = self.grid3(self.curl(Gh))
+            F1 = self.coeff3(self.cross(om, self.Ug))
+            if self.cost == "Integrated":
+                F1 = F1 - 2. * Bf_h
+            F2 = self.coeff3(self.cross(om, Bf))
+            nu_old = nu
+
+            def f(s, F2=F2, nu_old=nu_old):
+                K, k2s, v = self.K[:, s], self.k2s[s], nu_old[:, s]
+                f2 = -F2[:, s]
+                nn = v - 2. * K * ((K * v).sum(0) / k2s) + dt * (f2 - K * ((K * f2).sum(0) / k2s))
+                z = self.zero[s]
+                nn[:, z] = -v[:, z]
+                return nn
+            nu = self._over_kx(f)
+            Gh = self.cnab_update(Gh, F1)
+        gB = self.coeff_to_vec(dt * self.alpha * Gh) if Adjoint_type == "Discrete" else self.coeff_to_vec(Gh)
+        return [gB, self.coeff_to_vec(nu)]

@@ -443,10 +443,33 @@ class MultiContext(Context):
         self._describe()
         self.batch = 1
 
-    def _check_dev(self, vecs, who):           # per-device slab pointers: ncomp * ndev of them (lengths are the caller's business)
-        want = (2 if who == "inner" else self.ncomp) * len(self.devices)
+    def _check_dev(self, vecs, who):
+        """Per-device slab pointers, component-major: ncomp * ndev of them.  A slab of the wrong length or on the wrong device would be a GPU
+        memory fault inside a worker thread, not an exception: every slab that describes itself (DeviceVector, torch tensor) is
+        checked; raw integer addresses are the caller's business, as across the C-ABI."""
+        nd = len(self.devices)
+        want = (2 if who == "inner" else self.ncomp) * nd
         if len(vecs) != want:
-            raise ValueError("%s: %d slab pointers given, %d components x %d devices expected" % (who, len(vecs), self.ncomp, len(self.devices)))
+            raise ValueError("%s: %d slab pointers given, %d components x %d devices expected" % (who, len(vecs), self.ncomp, nd))
+        n_slab = self.vec_len // nd
+        for k, v in enumerate(vecs):
+            if v is None:
+                raise ValueError("%s: slab pointer %d is None" % (who, k))
+            if isinstance(v, int):
+                continue
+            n = getattr(v, "n", None)
+            if n is None and hasattr(v, "numel"):
+                n = v.numel()
+                if getattr(v, "dtype", None) is not None and getattr(v.dtype, "itemsize", 8) != 8:
+                    raise ValueError("%s: float64 slabs expected, got %s" % (who, v.dtype))
+                if hasattr(v, "is_contiguous") and not v.is_contiguous():
+                    raise ValueError("%s: contiguous slabs expected" % who)
+            if n is not None and int(n) != n_slab:
+                raise ValueError("%s: slab %d has %d entries, the context expects %d (= vec_len / %d devices)" % (who, k, int(n), n_slab, nd))
+            dev = getattr(v, "device", None)
+            idx = dev if isinstance(dev, int) else getattr(dev, "index", None)
+            if idx is not None and int(idx) != self.devices[k % nd]:
+                raise ValueError("%s: slab %d lives on device %d, rank %d of the context on device %d" % (who, k, int(idx), k % nd, self.devices[k % nd]))
 
     # -- vectors that stay distributed over the devices (devvec.MultiDeviceVector): no PCIe traffic, no host algebra on full-size vectors --------
     @staticmethod

@@ -98,10 +98,12 @@ int smo_get(const smo_ctx* ctx, int key, double* value) {
     return SMO_OK;
 }
 
-static int check_vecs(const smo_ctx* ctx, const double* const* X, const char* who) {
+// `dev`: the list holds device pointers (a multi-device context then dereferences one slab per component AND device: every one is checked)
+static int check_vecs(const smo_ctx* ctx, const double* const* X, const char* who, bool dev = false) {
     if (!X) { smo::set_error("%s: null vector list", who); return SMO_ERR_ARG; }
-    for (int c = 0; c < ctx->impl->n_comp; ++c)
-        if (!X[c]) { smo::set_error("%s: component %d is null", who, c); return SMO_ERR_ARG; }
+    const int n = dev ? ctx->impl->n_dev_ptrs() : ctx->impl->n_comp;
+    for (int c = 0; c < n; ++c)
+        if (!X[c]) { smo::set_error("%s: pointer %d of %d is null", who, c, n); return SMO_ERR_ARG; }
     return SMO_OK;
 }
 
@@ -113,13 +115,13 @@ int smo_forward(smo_ctx* ctx, const double* const* X, double* J) {
 }
 int smo_forward_dev(smo_ctx* ctx, const double* const* X, double* J) {
     CHECK_CTX(ctx);
-    SMO_TRY(check_vecs(ctx, X, "smo_forward_dev"));
+    SMO_TRY(check_vecs(ctx, X, "smo_forward_dev", true));
     if (!J) return SMO_ERR_ARG;
     SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
     return ctx->impl->forward_dev(X, J);
 }
 
-static int check_adjoint(smo_ctx* ctx, int adjoint_type, double* const* grad) {
+static int check_adjoint(smo_ctx* ctx, int adjoint_type, double* const* grad, bool dev = false) {
     if (adjoint_type != SMO_ADJ_DISCRETE && adjoint_type != SMO_ADJ_CONTINUOUS) {
         smo::set_error("smo_adjoint: adjoint_type %d", adjoint_type);
         return SMO_ERR_ARG;
@@ -128,7 +130,7 @@ static int check_adjoint(smo_ctx* ctx, int adjoint_type, double* const* grad) {
         smo::set_error("smo_adjoint: no forward solve on this context yet (the adjoint replays its snapshot stack)");
         return SMO_ERR_STATE;
     }
-    return check_vecs(ctx, grad, "smo_adjoint(grad)");
+    return check_vecs(ctx, grad, "smo_adjoint(grad)", dev);
 }
 int smo_adjoint(smo_ctx* ctx, const double* const* X, int adjoint_type, double* const* grad) {
     CHECK_CTX(ctx);
@@ -137,7 +139,7 @@ int smo_adjoint(smo_ctx* ctx, const double* const* X, int adjoint_type, double* 
 }
 int smo_adjoint_dev(smo_ctx* ctx, const double* const* X, int adjoint_type, double* const* grad) {
     CHECK_CTX(ctx);
-    SMO_TRY(check_adjoint(ctx, adjoint_type, grad));
+    SMO_TRY(check_adjoint(ctx, adjoint_type, grad, true));
     SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
     return ctx->impl->adjoint_dev(X, adjoint_type, grad);
 }
@@ -156,7 +158,9 @@ int smo_inner_dev(smo_ctx* ctx, const double* x, const double* y, double* out) {
 
 int smo_inner_slabs(smo_ctx* ctx, const double* const* x, const double* const* y, double* out) {
     CHECK_CTX(ctx);
-    if (!x || !y || !out || !x[0] || !y[0]) { smo::set_error("smo_inner_slabs: null argument"); return SMO_ERR_ARG; }
+    if (!x || !y || !out) { smo::set_error("smo_inner_slabs: null argument"); return SMO_ERR_ARG; }
+    for (int i = 0; i < ctx->impl->n_slabs(); ++i)
+        if (!x[i] || !y[i]) { smo::set_error("smo_inner_slabs: slab %d of %d is null", i, ctx->impl->n_slabs()); return SMO_ERR_ARG; }
     SMO_HIP(hipSetDevice(ctx->impl->cfg.device));
     return ctx->impl->inner_slabs(x, y, out);
 }
@@ -209,7 +213,7 @@ int smo_comm_set_transport(smo_ctx* ctx, smo_alltoall_fn a2a, smo_allreduce_fn a
 const char* smo_comm_library(void) { return smo::SlabComm::library_path(); }
 int smo_comm_get(const smo_ctx* ctx, int key, double* value) {
     CHECK_CTX(ctx);
-    if (!value || key < 0 || key > 2) { smo::set_error("smo_comm_get: bad argument"); return SMO_ERR_ARG; }
+    if (!value || key < 0 || key > 4) { smo::set_error("smo_comm_get: bad argument"); return SMO_ERR_ARG; }
     *value = ctx->impl->comm_info(key);
     return SMO_OK;
 }
@@ -222,6 +226,7 @@ int smo_set_stream(smo_ctx* ctx, void* hip_stream) {
 
 int smo_timing_enable(smo_ctx* ctx, int on) {
     CHECK_CTX(ctx);
+    if (on < 0 || on - 2 >= 64) { smo::set_error("smo_timing_enable: on = %d (0, 1, or 2 + class index < 64)", on); return SMO_ERR_ARG; }
     ctx->impl->tm().reset();
     ctx->impl->tm().on = (on != 0);
     ctx->impl->tm().mask = (on >= 2) ? (1ull << (on - 2)) : ~0ull;

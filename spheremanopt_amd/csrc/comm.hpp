@@ -11,6 +11,7 @@
 #pragma once
 #include "smo_common.hpp"
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 
@@ -27,7 +28,14 @@ namespace smo {
 //            -- host barrier --
 //            wait ev_pulled[p] of every peer: from here on my src may be overwritten
 // The host barriers only order the *calls* (an event must have been recorded before another thread may wait for it); the data dependencies
-// stay on the GPUs.  A rank that fails raises `failed` and releases the others, so a collective never hangs the process.
+// stay on the GPUs.  They are generation-counter SPIN barriers (round 4): a step pair has 8 exchanges = 16 rendezvous of W threads, and a
+// mutex / condition-variable rendezvous costs a futex wake per thread (tens of microseconds with 8 workers) where the kernels of a 256^3 / 8
+// step pair take 0.56 ms; the spin form costs a cache-line bounce (it yields the core after a few thousand polls, so oversubscribed hosts
+// still make progress).  A rank that fails raises `failed` and releases the others, so a collective never hangs the process.
+// The events carry hipEventReleaseToSystem: the producer's writes must be visible to a KERNEL running on another device (the gather kernel
+// reads the peers' buffers directly), not only to a copy engine.  Until a node with >= 2 GPUs has run tests/test_kdyn_multi_gpu.py the
+// gather kernel is the default only between ranks that share a device; distinct devices default to the hipMemcpyPeerAsync calls
+// (SMO_PEER_COPY=kernel / memcpy force one; use_kernel / smo_comm_get key 3 report the choice).
 class PeerGroup {
 public:
     explicit PeerGroup(const std::vector<int>& devices);
@@ -40,14 +48,14 @@ public:
     std::vector<int> dev;
     bool peer_access = false;           // hipDeviceEnablePeerAccess succeeded for every pair of distinct devices
     bool use_kernel = false;            // pulls as one gather kernel reading the peers' buffers directly (else hipMemcpyPeerAsync calls)
+    bool distinct = false;              // at least two ranks sit on different devices (bytes really cross the links)
+    unsigned long long barriers = 0;    // rendezvous passed by rank 0 (diagnostics: smo_comm_get key 4)
 
 private:
     int barrier();                      // SMO_OK, or SMO_ERR_STATE when a rank has failed
-    std::mutex mu;
-    std::condition_variable cv;
-    int waiting = 0;
-    unsigned long generation = 0;
-    bool failed = false;
+    alignas(64) std::atomic<int> waiting{0};
+    alignas(64) std::atomic<unsigned long> generation{0};
+    alignas(64) std::atomic<bool> failed{false};
     std::vector<const void*> pub_src;
     std::vector<void*> pub_dst;
     std::vector<hipEvent_t> ev_ready, ev_pulled;

@@ -1,4 +1,6 @@
 // Host plumbing of libsmo (no kernels here).
+#include <cstdlib>
+
 #include "smo_common.hpp"
 
 namespace smo {
@@ -64,7 +66,9 @@ void Timing::reset() {
     for (auto& n : seen) n = 0;
 }
 void Timing::begin(int k, hipStream_t s) {
-    Pending p{k, get(), get()};
+    static const bool env_pre = [] { const char* e = getenv("SMO_TIMING_PRE_MARKER"); return !(e && atoi(e) == 0); }();
+    Pending p{k, get(), get(), nullptr};
+    if (pre_marker && env_pre) { p.pre = get(); (void)hipEventRecord(p.pre, s); }
     (void)hipEventRecord(p.a, s);
     pend.push_back(p);
 }
@@ -81,6 +85,7 @@ int Timing::flush() {
         }
         free_ev.push_back(p.a);
         free_ev.push_back(p.b);
+        if (p.pre) free_ev.push_back(p.pre);
     }
     pend.clear();
     return SMO_OK;

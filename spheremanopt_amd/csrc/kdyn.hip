@@ -330,6 +330,8 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     // position-major tile (PosMajor, fft_lds.hpp): the ZT columns of a tile interleaved, every stage access of a wave is one contiguous
     // run (model: G = 192 reads 2x -> 1x, G = 384 3x -> 1x conflict cycles against rows of L + 1)
     constexpr PosMajor<ZT> ix{};
+    // the z-block-major Ty addressing below (trow, tys = 8) is written for tiles that lie inside one block of 8 z columns
+    static_assert(ZT <= 8 && 8 % ZT == 0, "kd_y_pass: SMO_Y_ZT must divide 8 (z-block-major Ty)");
     __shared__ cplx buf[ZT * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -955,7 +957,7 @@ public:
     double *d_U = nullptr, *d_part = nullptr;
     std::vector<double> h_part;
     size_t n_part_rows = 1;
-    int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1, k_ex = -1;
+    int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1, k_ex = -1, k_dot = -1;
 
     // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time
     int ck = 1, scratch_window = -1;
@@ -1146,6 +1148,8 @@ public:
         // slab transposes: HIP events around every grouped send/recv on the stream it is issued on (one field group of one rank, all
         // peers, as the byte figure; an adjoint step without kept grid states sends two groups in one call)
         k_ex = timing.add_class("slab_exchange(all-to-all)", 16.0 * tzb * W, 0.0);
+        // Inner_Prod_3 (FWD_Solve_KDyn.py:173-181; SURVEY.md 8d: "2 x (vector bytes)" per call — 340 MB at 128^3, 2.72 GB at 256^3)
+        k_dot = timing.add_class("kd_dot(inner product)", 2.0 * 8.0 * (double)n_grid);
         return SMO_OK;
     }
 
@@ -1598,7 +1602,8 @@ public:
     double comm_info(int key) const override {
         if (key == 0) return (double)K;
         if (key == 1) return 3.0 + (d_tystack ? 1.0 : 2.0);
-        return comm.is_rccl() ? 1.0 : 0.0;
+        if (key == 2) return comm.is_rccl() ? 1.0 : 0.0;
+        return 0.0;                               // keys 3, 4: the multi-device context's transport (csrc/multi.cpp)
     }
 
     // ---- the three callbacks: phases back to back; with slabs the transposes in between go through the communicator ------------
@@ -1750,7 +1755,10 @@ public:
     }
 
     int inner_dev(const double* x, const double* y, double* out) override {       // <x,y>; slabs without a communicator: this slab's share
-        hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
+        {
+            ScopedTimer t(timing, k_dot, stream);
+            hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
+        }
         SMO_HIP(hipGetLastError());
         double s = 0.0;
         SMO_TRY(reduce_partials(&s));

@@ -5,11 +5,13 @@
 // reference's full flat vectors [3][G][G][G]; the library
 //   * creates one KDYN slab context per device (rank i of ndev, csrc/kdyn.hip — the same kernels and the same in-library time loop as with one
 //     process per GPU) and joins them in a PeerGroup (csrc/comm.hpp): a transpose = every rank pulling its blocks from the peers' send buffers
-//     with hipMemcpyPeerAsync over the node's point-to-point links, ordered by HIP events; no RCCL, no launcher;
-//   * runs every collective call (forward, adjoint, inner product) on one worker thread per device — a single host thread cannot issue the
-//     launches of 8 GPUs fast enough (about 70 launches and as many event operations per step pair against 0.6 ms of kernels at 256^3 / 8);
+//     over the node's point-to-point links (one gather kernel, or hipMemcpyPeerAsync calls), ordered by HIP events; no RCCL, no launcher;
+//   * runs every collective call (forward, adjoint, inner product) on one PERSISTENT worker thread per device (created with the context,
+//     bound to its device once, woken per call) — a single host thread cannot issue the launches of 8 GPUs fast enough (about 70 launches
+//     and as many event operations per step pair against 0.6 ms of kernels at 256^3 / 8);
 //   * scatters X to / gathers grad J from the devices slab by slab (strided 2-D copies: z is the fastest axis and the one that is split).
 // A failing rank releases the others (PeerGroup::abort): the call returns its error instead of hanging.
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -29,30 +31,85 @@ public:
     std::vector<double*> sx[2], sg[2];              // per rank: device staging of X / grad (host-buffer entry points)
 
     ~MultiKDyn() override {
+        stop_workers();
         // members first: their destructors synchronise their streams on their own devices
         for (int i = 0; i < (int)r.size(); ++i) { (void)hipSetDevice(dev[i]); r[i].reset(); }
         grp.reset();
     }
 
-    // run f(rank) on one thread per device; first error wins (its message is carried to the calling thread)
-    template <class F> int on_all(F f) {
-        std::vector<int> rc(W, SMO_OK);
-        std::vector<std::string> msg(W);
-        grp->reset();
+    // ---- persistent workers: one host thread per device for the life of the context (round 3 spawned and joined W threads per call) ----
+    struct Pool {
         std::vector<std::thread> th;
-        for (int i = 0; i < W; ++i)
-            th.emplace_back([&, i]() {
-                if (hipSetDevice(dev[i]) != hipSuccess) { rc[i] = SMO_ERR_HIP; msg[i] = "hipSetDevice failed"; grp->abort(); return; }
-                rc[i] = f(i);
-                if (rc[i] != SMO_OK) { msg[i] = last_error(); grp->abort(); }
-            });
-        for (auto& t : th) t.join();
+        std::mutex mu;
+        std::condition_variable cv_job, cv_done;
+        std::function<int(int)> job;
+        unsigned long epoch = 0;
+        int done = 0;
+        bool quit = false;
+        std::vector<int> rc;
+        std::vector<std::string> msg;
+    } pool_;
+    void worker(int i) {
+        const bool bound = hipSetDevice(dev[i]) == hipSuccess;
+        unsigned long seen = 0;
+        for (;;) {
+            std::function<int(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(pool_.mu);
+                pool_.cv_job.wait(lk, [&] { return pool_.quit || pool_.epoch != seen; });
+                if (pool_.quit) return;
+                seen = pool_.epoch;
+                f = pool_.job;
+            }
+            int rc = SMO_OK;
+            std::string msg;
+            if (!bound) { rc = SMO_ERR_HIP; msg = "hipSetDevice failed"; }
+            else { rc = f(i); if (rc != SMO_OK) msg = last_error(); }
+            if (rc != SMO_OK) grp->abort();              // release the ranks that wait for this one in a collective
+            {
+                std::lock_guard<std::mutex> lk(pool_.mu);
+                pool_.rc[i] = rc; pool_.msg[i] = msg;
+                if (++pool_.done == W) pool_.cv_done.notify_one();
+            }
+        }
+    }
+    void start_workers() {
+        pool_.rc.assign(W, SMO_OK); pool_.msg.assign(W, std::string());
+        for (int i = 0; i < W; ++i) pool_.th.emplace_back([this, i] { worker(i); });
+    }
+    void stop_workers() {
+        { std::lock_guard<std::mutex> lk(pool_.mu); pool_.quit = true; }
+        pool_.cv_job.notify_all();
+        for (auto& t : pool_.th) if (t.joinable()) t.join();
+        pool_.th.clear();
+    }
+    // run f(rank) on every device's worker; first error wins (its message is carried to the calling thread)
+    int on_all(std::function<int(int)> f) {
+        if (pool_.th.empty()) { set_error("multi-device context: no worker threads"); return SMO_ERR_STATE; }
+        grp->reset();
+        {
+            std::unique_lock<std::mutex> lk(pool_.mu);
+            pool_.job = std::move(f);
+            pool_.done = 0;
+            ++pool_.epoch;
+            pool_.cv_job.notify_all();
+            pool_.cv_done.wait(lk, [&] { return pool_.done == W; });
+            pool_.job = nullptr;
+        }
+        const std::vector<int>& rc = pool_.rc;
+        const std::vector<std::string>& msg = pool_.msg;
         // report the rank that failed on its own, not the ones that were released from a collective because of it
         int bad = -1;
         for (int i = 0; i < W; ++i)
             if (rc[i] != SMO_OK && (bad < 0 || msg[bad].find("another rank of the multi-device context failed") != std::string::npos)) bad = i;
         if (bad >= 0) { set_error("device %d (rank %d of %d): %s", dev[bad], bad, W, msg[bad].c_str()); return rc[bad]; }
         return SMO_OK;
+    }
+    int n_dev_ptrs() const override { return 2 * W; }      // smo_forward_dev / smo_adjoint_dev: one slab pointer per (component, device)
+    int n_slabs() const override { return W; }
+    int set_stream(hipStream_t) override {
+        set_error("smo_set_stream: a multi-device context runs every rank on a private stream of its own device; a caller's stream cannot order them");
+        return SMO_ERR_UNSUPPORTED;
     }
 
     int init() override {
@@ -72,6 +129,7 @@ public:
         vec_len = (size_t)3 * G * G * G;                  // the caller's vectors are the reference's full ones
         cfg.device = dev[0];
         grp.reset(new PeerGroup(dev));
+        start_workers();
         r.resize(W);
         // members one after the other (each sizes its stack from the free HBM of its own device; several ranks may share a device in tests)
         for (int i = 0; i < W; ++i) {
@@ -176,11 +234,21 @@ public:
     }
     Timing& tm() override { return r[0]->timing; }
     int sync_all() override {
-        for (int i = 0; i < W; ++i) { SMO_HIP(hipSetDevice(dev[i])); SMO_HIP(hipStreamSynchronize(r[i]->stream)); }
-        return SMO_OK;
+        int cur = 0;
+        SMO_HIP(hipGetDevice(&cur));
+        int rc = SMO_OK;
+        for (int i = 0; i < W && rc == SMO_OK; ++i)
+            if (hipSetDevice(dev[i]) != hipSuccess || hipStreamSynchronize(r[i]->stream) != hipSuccess) { set_error("multi-device context: sync of device %d failed", dev[i]); rc = SMO_ERR_HIP; }
+        (void)hipSetDevice(cur);                           // the caller's current device is not ours to change
+        return rc;
     }
     double info(int key) const override { return r.empty() ? 0.0 : r[0]->info(key); }
-    double comm_info(int key) const override { return key == 2 ? 0.0 : (r.empty() ? 0.0 : r[0]->comm_info(key)); }
+    double comm_info(int key) const override {
+        if (key == 2) return 0.0;                          // no RCCL communicator here
+        if (key == 3) return grp ? (grp->use_kernel ? 2.0 : 1.0) : 0.0;      // transposes: 2 = gather kernel, 1 = hipMemcpyPeerAsync calls
+        if (key == 4) return grp ? (double)grp->barriers : 0.0;              // host rendezvous passed so far
+        return r.empty() ? 0.0 : r[0]->comm_info(key);
+    }
 };
 
 }  // namespace

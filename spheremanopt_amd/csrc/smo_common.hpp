@@ -89,6 +89,11 @@ public:
     bool on = false;
     unsigned long long mask = ~0ull;  // classes whose launches are timed (bit k = class k): keeps the event overhead out of the other launches
     int stride = 1;                   // of a selected class, every stride-th launch is timed (smo_timing_stride): a uniform sample at 1/stride of the event cost
+    // A start event recorded straight behind an UN-timed kernel reads early: the queue's marker packet is picked up while that kernel's last
+    // workgroups still run, so the interval includes the predecessor's tail (round 3: the every-8th-launch sample read 2.4-4.6 % above the
+    // every-launch average, where each start event follows the previous launch's END event).  pre_marker = true records one more event
+    // ahead of the start event, which absorbs that tail: begin = [pre][a], the interval is a..b as before.  SMO_TIMING_PRE_MARKER=0 disables.
+    bool pre_marker = true;
     std::vector<long long> seen;      // launches of each class since the last reset, timed or not
     std::vector<TimingClass> cls;
     int add_class(const char* name, double bytes, double hbm = -1.0) {
@@ -102,7 +107,7 @@ public:
     int flush();                      // resolve pending event pairs (after a stream sync)
     ~Timing();
 private:
-    struct Pending { int k; hipEvent_t a, b; };
+    struct Pending { int k; hipEvent_t a, b, pre; };
     std::vector<Pending> pend;
     std::vector<hipEvent_t> free_ev;
     hipEvent_t get();
@@ -111,7 +116,7 @@ private:
 struct ScopedTimer {
     Timing& t; int k; hipStream_t s;
     bool active;
-    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && ((t_.mask >> k_) & 1ull)) {
+    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && k_ < 64 && ((t_.mask >> k_) & 1ull)) {
         if (active && t.stride > 1) active = (t.seen[k]++ % t.stride) == 0;
         if (active) t.begin(k, s);
     }
@@ -164,7 +169,10 @@ public:
     virtual double comm_info(int key) const { (void)key; return 0.0; }
     // ranks of ONE process (smo_create_multi): the context becomes rank `rank` of the group; collective like comm_init
     virtual int comm_set_peers(class PeerGroup* g, int rank) { (void)g; (void)rank; set_error("multi-device contexts: KDYN only"); return SMO_ERR_UNSUPPORTED; }
-    int set_stream(hipStream_t s);      // run on a caller-owned stream (e.g. torch's current stream) instead of the private one
+    virtual int set_stream(hipStream_t s);      // run on a caller-owned stream (e.g. torch's current stream) instead of the private one
+    // device pointers the _dev entry points dereference (a multi-device context: one slab per component and device), slabs of smo_inner_slabs
+    virtual int n_dev_ptrs() const { return n_comp; }
+    virtual int n_slabs() const { return 1; }
 
     // host-buffer variants: stage through context-owned device vectors (a multi-device context scatters / gathers slabs instead)
     virtual int forward_host(const double* const* X, double* J);

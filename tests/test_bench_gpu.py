@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -39,6 +40,12 @@ def test_kdyn_line_contract():
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     # the dominant class carries HIP events on every 8th of its launches inside the timed region (a uniform sample)
     assert r["timing_stride"] == 8 and 1 <= r["launches_timed"] <= (2 * 2 * 22 + 7) // 8      # a class is launched at most ~2x per time step
+    # frac is taken from the sample inside the timed region; the warm-up gradient's every-launch average rides along
+    assert r["avg_launch_ms"] == r["avg_launch_ms_sampled"] and r["avg_launch_ms_every_launch"] > 0 and "avg_launch_ms_sampled" in r["frac_basis"]
+    assert abs(r["frac_every_launch"] - r["bytes_per_launch"] / (r["avg_launch_ms_every_launch"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    # Inner_Prod_3 is part of SURVEY 8d's measurement: 2 x vector bytes per call, timed with HIP events, checked against NumPy's value
+    ip = r["inner_product"]
+    assert "error" not in ip and ip["bytes_per_call"] == 2 * 8 * 3 * 48 ** 3 and ip["launches_timed"] == 20 and 0 < ip["frac"] <= 1.0 and ip["wall_ms_per_call"] > 0
     # no PMC summary of a 32^3 run is committed: traffic must be null with the reason, not a number from another build / size
     assert r["traffic"] is None and "reason" in r["traffic_source"]
     # `value` is SURVEY 8d's metric: the timed steps hand over HOST vectors (H2D of X and D2H of grad J inside the timed region); the
@@ -51,6 +58,10 @@ def test_kdyn_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    # the all-core leg is pinned to ONE socket's physical cores and says which CPU that is
+    ac = d["config"]["cpu_single_socket"]
+    assert ac["cores"] >= 1 and ac["value"] > 0 and ac["scaling_over_1_core"] > 0 and "model" in ac["cpu"] and ac["cpu"]["sockets"] is not None
+    assert ac["cores"] <= (ac["cpu"]["physical_cores_per_socket"] or ac["cores"])
 
 
 def test_single_process_multi_device_line():
@@ -62,6 +73,25 @@ def test_single_process_multi_device_line():
     assert c["compute_ms_per_step_pair"] > 0 and c["exchange_ms_per_step_pair"] > 0 and c["wall_ms_per_step_pair"] > 0
     one = _run(["--npts", "32", "--iters", "20", "--steps", "1", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"])
     assert abs(c["J"] - one["config"]["J"]) <= 1e-12 * abs(one["config"]["J"])
+    # the transport in use is named (ranks sharing a device: the gather kernel) and the host side of the loop is measured
+    assert "gather kernel" in c["transpose_pull"] and c["host_issue"]["workers"] == 2 and c["host_issue_ms_per_step_pair"] > 0
+    assert 15.5 <= c["host_issue"]["rendezvous_per_step_pair"] <= 17.5      # 4 exchanges forward + 4 adjoint per step pair, two rendezvous each (+ the transforms of X / the gradients)
+
+
+def test_single_process_line_at_the_north_star_decomposition(fields384):
+    """`--devices 0 x 8 --npts 256 --iters 20`: config 5's decomposition (16 kx planes / 48 z planes per rank, G = 384 kernels, default chunks)
+    through the benchmark's own single-process path, eight persistent workers."""
+    d = _run(["--devices", "0,0,0,0,0,0,0,0", "--npts", "256", "--iters", "20", "--steps", "1", "--warmup", "1"])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and c["devices"] == [0] * 8 and c["chunks"] == 1 and c["grid"] == [384, 384, 384]
+    assert np.isfinite(c["J"]) and c["compute_ms_per_step_pair"] > 0 and c["exchange_ms_per_step_pair"] > 0
+    hi = c["host_issue"]
+    assert hi["workers"] == 8 and hi["chunks"] == 1 and 0 < c["host_issue_ms_per_step_pair"] < 5.0
+    from spheremanopt_amd import _capi
+    one = _capi.Context(_capi.SMO_KDYN, 256, (0., 2. * np.pi), 1e-3, 20, 1.0)           # the same 20 steps on the plain single-GPU context
+    J1 = one.forward(list(fields384))
+    one.close()
+    assert abs(c["J"] - J1) <= 1e-12 * abs(J1)
 
 
 @pytest.mark.parametrize("wl", ["sh23", "shb23", "pois"])

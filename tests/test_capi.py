@@ -139,3 +139,10 @@ def test_bound_librccl_is_reported(L):
     assert p.returncode == 0, p.stderr
     line = [l for l in p.stdout.splitlines() if l.startswith("LIB")][0]
     assert "librccl" in line and os.path.exists(line.split(None, 1)[1])
+
+
+def test_product_library_directory_holds_only_the_product(L):
+    """experimental (deliberately miscompiled) builds live under tools/bin/ or xp_tmp/, never beside the product
+    library, where a glob or a stray SMO_LIB could pick them up."""
+    libdir = os.path.join(ROOT, "spheremanopt_amd", "lib")
+    assert sorted(f for f in os.listdir(libdir) if not f.startswith(".")) == ["libsmo.so"]

@@ -122,6 +122,85 @@ def test_multi_device_context_at_the_bench_grid_against_the_oracle_fixture():
     ctx.close()
 
 
+def _check_against(gold, J, g, key):
+    Jo = float(gold["J_" + key.split("_")[0]])
+    assert abs(J - Jo) <= RTOL * abs(Jo), (key, J, Jo)
+    idx = gold["idx"]
+    for name, v in (("gB", g[0]), ("gU", g[1])):
+        ref = gold["%s_%s" % (key, name)]
+        assert np.linalg.norm(v[idx] - ref) <= RTOL * np.linalg.norm(ref), (key, name)
+        nrm = float(gold["%s_%s_norm" % (key, name)])
+        assert abs(np.linalg.norm(v) - nrm) <= RTOL * nrm, (key, name)
+
+
+def test_multi_device_context_at_the_north_star_grid_8_way(monkeypatch, fields384):
+    """BASELINE configs[4]'s decomposition — 256^3 over EIGHT ranks (16 kx planes, 48 z planes = 6 z-blocks per rank, the G = 384 kernels, default
+    chunk count) — through ONE multi-device context with the box's GPU listed eight times, against the oracle fixture: both cost functionals,
+    both adjoints, both pull implementations, keep-all and windowed checkpoints.  Reference: FWD_Solve_KDyn.py:118-134 under
+    `mpiexec -np 8` (README.md:83)."""
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c5_256_n2.npz"))
+    N, n, devs = 256, 2, [0] * 8
+    B, U = fields384
+    first = None
+    for cost, adj, pull, ckpt in (("Final", "Discrete", "kernel", 1), ("Integrated", "Continuous", "memcpy", 2), ("Final", "Discrete", "memcpy", 2)):
+        monkeypatch.setenv("SMO_PEER_COPY", pull)
+        ctx = _capi.MultiContext(N, (0., 2. * np.pi), 1e-3, n, 1.0, devs, cost=cost, ckpt=ckpt)
+        assert ctx.comm_get(0) == 1 and ctx.get(0) == ckpt               # default chunk count at 256^3 / 8; the interval asked for
+        assert ctx.comm_get(3) == (2 if pull == "kernel" else 1)          # the pull implementation in use is reported
+        J = ctx.forward([B, U])
+        g = [v.copy() for v in ctx.adjoint(None, adj)]
+        ctx.close()
+        _check_against(gold, J, g, "%s_%s" % (cost, adj))
+        if (cost, adj) == ("Final", "Discrete"):
+            if first is None:
+                first = (J, g)
+            else:                                                        # other transport, recomputed windows: the same bits
+                assert J == first[0] and np.array_equal(g[0], first[1][0]) and np.array_equal(g[1], first[1][1])
+
+
+def test_multi_device_context_at_the_bench_grid_8_way():
+    """128^3 over eight ranks (8 kx planes, 24 z planes per rank: the halved y-pass tile) against the committed 50-step oracle run."""
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c4_128_n50.npz"))
+    N, n = 128, 50
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    ctx = _capi.MultiContext(N, (0., 2. * np.pi), 1e-3, n, 1.0, [0] * 8, cost="Integrated")
+    J = ctx.forward([B, U])
+    g = ctx.adjoint(None, "Discrete")
+    _check_against(gold, J, g, "Integrated_Discrete")
+    ctx.close()
+
+
+def test_null_and_short_slab_lists_are_argument_errors():
+    """a multi-device context dereferences one slab pointer per (component, device): every one is validated (C side: NULL ->
+    SMO_ERR_ARG; Python side: length and device of every slab that describes itself) instead of faulting inside a worker thread."""
+    import ctypes as C
+    import torch
+    ctx = _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 2, 1.0, [0, 0])
+    n_slab = ctx.vec_len // 2
+    good = [torch.zeros(n_slab, dtype=torch.float64, device="cuda:0") for _ in range(4)]
+    assert np.isfinite(ctx.forward_dev(good))
+    with pytest.raises(ValueError):
+        ctx.forward_dev(good[:3])                                                       # a short list
+    with pytest.raises(ValueError):
+        ctx.forward_dev(good[:3] + [torch.zeros(n_slab - 1, dtype=torch.float64, device="cuda:0")])      # a short slab
+    J = np.zeros(1)
+    ptrs = _capi._ptr_array([_capi._dev_ptr(t) for t in good[:3]] + [None])             # straight through the C-ABI: a NULL among the 2 * ndev
+    rc = _capi.lib().smo_forward_dev(ctx._h, ptrs, J.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 1 and b"pointer 3 of 4 is null" in _capi.lib().smo_last_error()
+    out = np.zeros(1)
+    xs = _capi._ptr_array([_capi._dev_ptr(good[0]), None])
+    rc = _capi.lib().smo_inner_slabs(ctx._h, xs, xs, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 1 and b"slab 1 of 2 is null" in _capi.lib().smo_last_error()
+    rc = _capi.lib().smo_set_stream(ctx._h, None)
+    assert rc == 6 and b"private stream" in _capi.lib().smo_last_error()                 # SMO_ERR_UNSUPPORTED
+    ctx.close()
+
+
 def test_null_transport_runs_one_ranks_share():
     """smo_comm_set_transport(ctx, NULL, NULL, NULL): rank 0 of a 4-way decomposition runs its kernels through the real in-library loop with no
     exchange at all (tools/prof_slab_geometry.py); results are meaningless, the call sequence must simply complete and be timed."""

@@ -289,6 +289,58 @@ def test_bench_size_slabs_agree_with_the_single_gpu_path(tmp_path, N, world, chu
             assert abs(np.linalg.norm(r[name]) - nrm) <= 1e-6 * nrm
 
 
+def _against_c5_fixture(J, gB, gU, key="Final_Discrete"):
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c5_256_n2.npz"))
+    assert int(gold["N"]) == 256 and int(gold["steps"]) == 2 and float(gold["dt"]) == 1e-3 and float(gold["Rm"]) == 1.0
+    Jo, idx = float(gold["J_" + key.split("_")[0]]), gold["idx"]
+    assert abs(J - Jo) <= 1e-6 * abs(Jo), (J, Jo)
+    for name, v in (("gB", gB), ("gU", gU)):
+        ref = gold["%s_%s" % (key, name)]
+        assert np.linalg.norm(v[idx] - ref) <= 1e-6 * np.linalg.norm(ref), name
+        nrm = float(gold["%s_%s_norm" % (key, name)])
+        assert abs(np.linalg.norm(v) - nrm) <= 1e-6 * nrm, name
+
+
+def test_north_star_decomposition_8_way_in_library_loop(fields384):
+    """BASELINE configs[4] exactly as `bench.py --gpus 8` decomposes it — 256^3, W = 8: 16 kx planes and 48 z planes (6 z-blocks) per rank, the
+    G = 384 kernels, the library's DEFAULT chunk count — through the in-library loop and the callback transport, against the oracle fixture
+    (the scaling node must not be the first execution of this geometry).  The 8 ranks are threads of this process
+    (tests/thread_ranks.py): the box allows 6 processes on its GPU, so 8 gloo ranks cannot share it.  Reference: FWD_Solve_KDyn.py:118-134
+    under `mpiexec -np 8` (README.md:83)."""
+    from spheremanopt_amd import kdyn
+    from thread_ranks import slab_gradient
+    N, W, n = 256, 8, 2
+    B, U = fields384
+    J, gB, gU, K, nex = slab_gradient(N, W, n, B, U, "Final", "Discrete")
+    assert K == 1                                  # the default at 256^3 / 8: G * Gzr / 36864 < 1 chunk of a plane set -> no pipelining
+    assert nex >= 3 + 4 * n + 3                    # U, B in; 4 exchanges per step pair; the two gradients and nu out
+    _against_c5_fixture(J, gB, gU)
+    # ... and with two pipelined chunks (24 z planes = 3 z-blocks each: the chunk-major exchange layout at this geometry), bit for bit
+    J2, gB2, gU2, K2, _ = slab_gradient(N, W, n, B, U, "Final", "Discrete", chunks=2)
+    assert K2 == 2 and J2 == J and np.array_equal(gB2, gB) and np.array_equal(gU2, gU)
+
+
+def test_bench_grid_8_way_thin_slabs_in_library_loop():
+    """128^3 at W = 8 (what `bench.py --gpus 8` times as its main line): 8 kx planes and 24 z planes per rank — the halved y-pass tile (24 % 8 == 0
+    but Gzr / ZT = 3 tiles; x tiles of 8 points over 192 x 24 planes) — one chunk, against the single-GPU path (itself checked against the
+    oracle at this grid: tests/test_kdyn_gpu.py) on the same inputs: same kernels, another summation order only in J."""
+    from spheremanopt_amd import kdyn
+    from thread_ranks import slab_gradient
+    N, W, n = 128, 8, 3
+    G = 3 * N // 2
+    B, U = kdyn.synthetic_field(G, 1), kdyn.synthetic_field(G, 2)
+    dom = kdyn.KDynDomain(N)
+    args = [dom, 1., 1e-3, n, n, kdyn.GEN_BUFFER(N, dom, n), "Integrated", "Continuous"]
+    J0 = kdyn.FWD_Solve_IVP_Lin([B, U], *args)
+    g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], *args)
+    dom.drop_contexts()
+    J, gB, gU, K, _ = slab_gradient(N, W, n, B, U, "Integrated", "Continuous")
+    assert K == 1
+    assert abs(J - J0) <= 1e-12 * abs(J0)
+    assert rel(gB, g0[0]) < 1e-12 and rel(gU, g0[1]) < 1e-12
+
+
 def test_communicator_errors():
     """world > 1 without a communicator: the loop entry points refuse (the phase-level entry still works); a single-slab context has
     nothing to exchange; smo_comm_get reports the pipeline."""

@@ -239,3 +239,19 @@ def test_kdyn_invariants():
     # transform round trip and layout: coeff -> grid -> coeff
     c = k.vec_to_coeff(B)
     assert np.allclose(k.vec_to_coeff(k.coeff_to_vec(c)), c, atol=1e-14)
+
+
+@pytest.mark.parametrize("cost,adj", [("Final", "Discrete"), ("Integrated", "Continuous")])
+def test_threaded_kdyn_oracle_is_the_same_restatement(cost, adj):
+    """bench.py's all-core CPU leg (oracle.kdyn.ThreadedKDynOracle: pointwise stages chunked over a thread pool) computes what KDynOracle
+    computes: gradients bit for bit, J to the rounding of the per-chunk grid mean."""
+    from oracle.kdyn import KDynOracle, ThreadedKDynOracle, synthetic_field
+    N, n = 16, 4
+    B, U = synthetic_field(24, 1), synthetic_field(24, 2)
+    o = KDynOracle(N, Rm=1., dt=1e-3, N_ITERS=n, Cost_function=cost)
+    J0 = o.forward([B, U]); g0 = o.adjoint([B, U], adj)
+    for threads in (1, 3):
+        t = ThreadedKDynOracle(N, Rm=1., dt=1e-3, N_ITERS=n, Cost_function=cost, threads=threads)
+        J1 = t.forward([B, U]); g1 = t.adjoint([B, U], adj)
+        assert abs(J1 - J0) <= 1e-14 * abs(J0)
+        assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[1], g0[1])

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Out-of-line device calls in the SHB23 any-N kernels (csrc/shb23.hip `DctWork<0>`).
 #   tools/run_outline_abi.sh build   (CPU box)  micro test + two experimental libsmo builds whose dct2<0>/dct3<0> are real calls:
-#        lib/libsmo_outline_A.so  the round-2 failing state: no inline attributes on dct2<0>/dct3<0>/load_tables<0>/the kernels' lambdas
-#        lib/libsmo_outline_B.so  today's sources with dct3<0> alone marked noinline
+#        tools/bin/libsmo_outline_A.so  the round-2 failing state: no inline attributes on dct2<0>/dct3<0>/load_tables<0>/the kernels' lambdas
+#        tools/bin/libsmo_outline_B.so  today's sources with dct3<0> alone marked noinline
 #   tools/run_outline_abi.sh run     (GPU box)  micro modes 1..5, then tools/diag_outline_shb.py on the product build, A and B;
 #        every step under its own timeout, the chain stops at the first step that is killed; output under gpurun_out/outline/
 set -u
@@ -38,7 +38,7 @@ if [ "${1:-}" = build ]; then
         echo "variant $v ($extra): $(grep -c s_swappc_b64 "$W/shb23_$v-hip-amdgcn-amd-amdhsa-gfx950.s") out-of-line calls"
         [ -n "${KEEP_ISA:-}" ] && cp "$W/shb23_$v-hip-amdgcn-amd-amdhsa-gfx950.s" "$KEEP_ISA/shb23_$v.s"
         objs=$(ls "$CSRC"/build/*.o | grep -v shb23)
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "spheremanopt_amd/lib/libsmo_outline_$v.so" $objs "$W/shb23_$v.o" -ldl || exit 1
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "tools/bin/libsmo_outline_$v.so" $objs "$W/shb23_$v.o" -ldl || exit 1
     done
     rm -rf "$W"
     exit 0
@@ -54,7 +54,7 @@ for m in ${MICRO-1 2 3 4 5}; do
 done
 if [ $ok = 1 ]; then
     for v in product ${VARIANTS:-A B C D E F G}; do
-        lib=spheremanopt_amd/lib/libsmo_outline_$v.so
+        lib=tools/bin/libsmo_outline_$v.so
         [ $v = product ] && lib=spheremanopt_amd/lib/libsmo.so
         [ -f $lib ] || continue
         SMO_LIB=$ROOT/$lib timeout -k 10 240 python tools/diag_outline_shb.py > $OUT/diag_$v.txt 2>&1
