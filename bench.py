@@ -565,9 +565,11 @@ def bench_kdyn(a, torch, rank, world):
             # two views of the same kernel's launch time: the sample taken INSIDE the timed region (what `achieved` / `frac` use) and the
             # warm-up gradient's every-launch average (events around all classes: every kernel runs fenced, at ~9 % more wall time)
             "avg_launch_ms_sampled": avg_ms, "avg_launch_ms_every_launch": every_ms,
-            "frac_basis": "avg_launch_ms_sampled: every %d-th launch of the dominant class inside the timed region, each with a marker event "
-                          "ahead of its start event (SMO_TIMING_PRE_MARKER) so that the interval does not include the unfenced predecessor's tail"
-                          % TIMING_STRIDE,
+            "frac_basis": "avg_launch_ms_sampled: every %d-th launch of the dominant class INSIDE the timed region, begin / end timestamps of the "
+                          "dispatch itself (hipExtLaunchKernelGGL start / stop events: what rocprofv3 --kernel-trace reports, no marker packets "
+                          "in the queue).  The same kernel reads 3-5 %% shorter when every launch of every class is instrumented "
+                          "(avg_launch_ms_every_launch, and any rocprofv3 run): an instrumented queue has idle gaps between its kernels and the "
+                          "chip runs them at a higher clock (DESIGN.md section 5)" % TIMING_STRIDE,
             "frac_every_launch": rate(dom_k["hbm_bytes_per_launch"], every_ms) / 8000.0,
             "achieved_algorithmic": rate(dom_k["bytes_per_launch"], avg_ms), "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             "kernel_time_share": share,
@@ -631,9 +633,9 @@ def bench_kdyn(a, torch, rank, world):
     # series of device-resident calls, and the wall time of a call (kernel + the D2H of the 1024 partial sums + the host reduction)
     try:
         dot_i = [i for i, t in enumerate(tim) if t["kernel"].startswith("kd_dot")][0]
-        ctx.timing_enable(only=dot_i)
         nd = 20
         ctx.inner_dev(Bd, gB)
+        ctx.timing_enable(only=dot_i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(nd):
@@ -694,6 +696,9 @@ def bench_kdyn_multi(a, torch, devices):
     ex = [t2[i] for i in ex_i]
     pull = {2.0: "one gather kernel per exchange reading every peer's send buffer (peer access)", 1.0: "hipMemcpyPeerAsync, one call per peer"}.get(ctx.comm_get(3), "?")
     rendezvous = ctx.comm_get(4)
+    # host time the slowest worker spent ISSUING the last forward + adjoint solve (smo_get key 4: call entry until everything is enqueued, minus
+    # its waits for the other workers in host rendezvous), per step pair — at the bench grid itself
+    issue_ms = ctx.get(4) / n_iters
     # What the HOST costs per step pair with this many workers: the same loop at a grid whose kernels take microseconds (same launches, events and
     # spin-barrier rendezvous per step pair as at the bench grid; the GPU is never the bottleneck there), so its wall time per step pair is the
     # time the slowest worker needs to ISSUE a step pair — to be set against the kernels' time per step pair of the real grid.
@@ -711,10 +716,12 @@ def bench_kdyn_multi(a, torch, devices):
             th = time.perf_counter()
             for _ in range(3):
                 hctx.forward(hx); hctx.adjoint(None, out=hg)
-            host_issue = {"ms_per_step_pair": 1e3 * (time.perf_counter() - th) / 3 / hi, "grid": "%d^3" % Nh, "n_iters": hi, "workers": len(devices),
+            host_issue = {"wall_ms_per_step_pair": 1e3 * (time.perf_counter() - th) / 3 / hi, "issue_ms_per_step_pair": hctx.get(4) / hi,
+                          "grid": "%d^3" % Nh, "n_iters": hi, "workers": len(devices),
                           "chunks": int(hctx.comm_get(0)), "rendezvous_per_step_pair": (hctx.comm_get(4) - r0) / 3 / hi,
-                          "note": "wall time per step pair of the same multi-device loop at a grid whose kernels take microseconds: launches, event "
-                                  "records / waits and the two spin-barrier rendezvous per exchange, slowest worker"}
+                          "note": "the same multi-device loop at a grid whose kernels take microseconds (same launches, event records / waits and "
+                                  "spin-barrier rendezvous per step pair): wall time per step pair (an upper bound of the loop's fixed costs; with "
+                                  "all workers on ONE GPU it includes that GPU executing every rank's launches) and the slowest worker's issue time"}
             hctx.close()
     except Exception as e:
         host_issue = {"error": repr(e)}
@@ -727,7 +734,7 @@ def bench_kdyn_multi(a, torch, devices):
            "parallelism": "ONE process, slab x%d over devices %s (smo_create_multi: one persistent worker thread per device, transposes = peer pulls "
                           "ordered by HIP events — %s; no RCCL)" % (len(devices), list(devices), pull),
            "transpose_pull": pull, "host_rendezvous_per_step_pair": rendezvous / max(steps + max(warm, 1), 1) / n_iters,
-           "host_issue": host_issue, "host_issue_ms_per_step_pair": (host_issue or {}).get("ms_per_step_pair"),
+           "host_issue_ms_per_step_pair": issue_ms, "host_bound_loop": host_issue,
            "vectors": "host (pinned), the reference's full vectors: scatter of X and gather of grad J inside the timed region",
            "checkpoint_interval": int(ctx.get(0)), "chunks": int(ctx.comm_get(0)),
            "compute_ms_per_step_pair": sum(t["total_ms"] for t in tim if not t["kernel"].startswith("slab_exchange")) / max(warm, 1) / n_iters,

@@ -126,7 +126,9 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by t
  * multi-workgroup cluster to one workgroup per problem because a cluster all-gather timed out (a busy GPU);  key 2 (KDYN): number of
  * solves replayed from a captured HIP graph (small grids on one GPU: the whole forward solve / adjoint sweep is one graph launch); SHB23:
  * workgroups that co-operate on one problem (1 = no cluster: batch > 1, fewer than 256 modes, SMO_SHB_CLUSTER=0 or after a time-out);
- * key 3 (KDYN): layout of the y-transformed work fields, 0 = planes [c][kx][y][z], 1 = z-block major [c][z/8][kx][y][z%8]. */
+ * key 3 (KDYN): layout of the y-transformed work fields, 0 = planes [c][kx][y][z], 1 = z-block major [c][z/8][kx][y][z%8];
+ * key 4 (KDYN): milliseconds of HOST time the last smo_forward + smo_adjoint spent issuing work (entry of the call until everything is enqueued,
+ * minus the waits for other ranks in host rendezvous; a multi-device context reports its slowest worker) — to be set against the kernels' time. */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */

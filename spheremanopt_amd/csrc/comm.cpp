@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -143,9 +144,11 @@ __global__ __launch_bounds__(256) void peer_gather(double2* __restrict__ dst, Pe
 
 PeerGroup::PeerGroup(const std::vector<int>& devices) : dev(devices) {
     const int W = (int)dev.size();
-    pub_src.assign(W, nullptr); pub_dst.assign(W, nullptr);
+    pub_src.assign(2 * (size_t)W, nullptr); pub_dst.assign(2 * (size_t)W, nullptr);
+    seq.assign((size_t)W * 8, 0);
     ev_ready.assign(W, nullptr); ev_pulled.assign(W, nullptr);
     red.assign((size_t)W * 64, 0.0);
+    wait_ms.assign((size_t)W * 8, 0.0);          // (stride 8 doubles = one cache line per rank below: see barrier())
     peer_access = true;
     for (int r = 0; r < W; ++r) {
         if (hipSetDevice(dev[r]) != hipSuccess) { peer_access = false; continue; }
@@ -177,8 +180,12 @@ PeerGroup::~PeerGroup() {
         if (ev_pulled[r]) (void)hipEventDestroy(ev_pulled[r]);
     }
 }
-int PeerGroup::barrier() {
+int PeerGroup::barrier(int rank) {
     // generation-counter spin barrier: the last arrival resets the count and bumps the generation (release); the others poll it (acquire)
+    struct Waited {
+        double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Waited() { acc += 1e-6 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    } waited{wait_ms[(size_t)rank * 8]};
     if (failed.load(std::memory_order_acquire)) { set_error("another rank of the multi-device context failed"); return SMO_ERR_STATE; }
     const unsigned long gen = generation.load(std::memory_order_acquire);
     if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == world()) {
@@ -197,18 +204,20 @@ void PeerGroup::abort() { failed.store(true, std::memory_order_release); }
 void PeerGroup::reset() {
     failed.store(false, std::memory_order_release);
     waiting.store(0, std::memory_order_release);
+    for (size_t r = 0; r < dev.size(); ++r) seq[r * 8] = 0;      // (a failed call may have left the ranks at different counts)
 }
-int PeerGroup::alltoall(int rank, const void* src, void* dst, size_t bytes, hipStream_t s) {
+int PeerGroup::alltoall(int rank, const void* src, void* dst, size_t bytes, hipStream_t s, bool chained) {
     const int W = world();
-    pub_src[rank] = src; pub_dst[rank] = dst;
-    if (rank == 0) barriers += 2;
+    const size_t slot = (size_t)(seq[(size_t)rank * 8]++ & 1ul) * W;      // every rank runs the same sequence of exchanges: same parity everywhere
+    pub_src[slot + rank] = src; pub_dst[slot + rank] = dst;
+    if (rank == 0) barriers += chained ? 1 : 2;
     SMO_HIP(hipEventRecord(ev_ready[rank], s));
-    SMO_TRY(barrier());
+    SMO_TRY(barrier(rank));
     for (int p = 0; p < W; ++p)
         if (p != rank) SMO_HIP(hipStreamWaitEvent(s, ev_ready[p], 0));
     if (use_kernel && bytes % 16 == 0 && W <= 64) {
         PeerSrcs srcs{};
-        for (int p = 0; p < W; ++p) srcs.p[p] = static_cast<const double2*>(pub_src[p]);
+        for (int p = 0; p < W; ++p) srcs.p[p] = static_cast<const double2*>(pub_src[slot + p]);
         const size_t n2 = bytes / 16;
         const unsigned gx = (unsigned)std::min<size_t>(128, (n2 + 255) / 256);
         hipLaunchKernelGGL(peer_gather, dim3(gx, W), dim3(256), 0, s, static_cast<double2*>(dst), srcs, W, rank, n2);
@@ -216,14 +225,15 @@ int PeerGroup::alltoall(int rank, const void* src, void* dst, size_t bytes, hipS
     } else {
         for (int q = 0; q < W; ++q) {
             const int p = (rank + q) % W;                    // start with my own block, then walk the ring: the peers pull from different sources
-            const char* from = static_cast<const char*>(pub_src[p]) + (size_t)rank * bytes;
+            const char* from = static_cast<const char*>(pub_src[slot + p]) + (size_t)rank * bytes;
             char* to = static_cast<char*>(dst) + (size_t)p * bytes;
             if (dev[p] == dev[rank]) SMO_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
             else SMO_HIP(hipMemcpyPeerAsync(to, dev[rank], from, dev[p], bytes, s));
         }
     }
+    if (chained) return SMO_OK;                              // the next exchange's pull orders the re-use of `src` (comm.hpp)
     SMO_HIP(hipEventRecord(ev_pulled[rank], s));
-    SMO_TRY(barrier());
+    SMO_TRY(barrier(rank));
     for (int p = 0; p < W; ++p)
         if (p != rank) SMO_HIP(hipStreamWaitEvent(s, ev_pulled[p], 0));
     return SMO_OK;
@@ -232,13 +242,13 @@ int PeerGroup::allreduce_sum(int rank, double* vals, int n, hipStream_t s) {
     if (n > 64) { set_error("PeerGroup::allreduce_sum: at most 64 values"); return SMO_ERR_ARG; }
     SMO_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n; ++i) red[(size_t)rank * 64 + i] = vals[i];
-    SMO_TRY(barrier());
+    SMO_TRY(barrier(rank));
     for (int i = 0; i < n; ++i) {
         double a = 0.0;
         for (int p = 0; p < world(); ++p) a += red[(size_t)p * 64 + i];      // the same order on every rank: identical sums
         vals[i] = a;
     }
-    return barrier();                                        // nobody overwrites its slot before everyone has read it
+    return barrier(rank);                                    // nobody overwrites its slot before everyone has read it
 }
 SlabComm::~SlabComm() { reset(); }
 
@@ -247,8 +257,8 @@ const char* SlabComm::library_path() {
     return g_rccl.handle ? g_lib_path.c_str() : "";
 }
 
-int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s) {
-    if (peers_) return peers_->alltoall(rank, src, dst, bytes_per_peer, s);
+int SlabComm::alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s, bool chained) {
+    if (peers_) return peers_->alltoall(rank, src, dst, bytes_per_peer, s, chained);
     if (null_) return SMO_OK;
     if (nccl_) {
         ncclComm_t c = static_cast<ncclComm_t>(nccl_);

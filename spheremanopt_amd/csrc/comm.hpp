@@ -41,7 +41,12 @@ public:
     explicit PeerGroup(const std::vector<int>& devices);
     ~PeerGroup();
     int world() const { return (int)dev.size(); }
-    int alltoall(int rank, const void* src, void* dst, size_t bytes_per_peer, hipStream_t s);
+    // chained = true: the caller guarantees that the NEXT writer of `src` on this rank is the pull of a later exchange on the same stream
+    // (the time loop: transpose -> grid kernels -> transpose back -> per-mode update -> transpose ...).  That pull waits for every peer's
+    // ev_ready of its own exchange, which the peer records after its pull of THIS one — so "everybody has pulled my block" is already implied
+    // when it runs, and the second rendezvous, the ev_pulled record and the W - 1 waits on the peers' ev_pulled are left out: one rendezvous,
+    // one record, W - 1 waits and one launch per exchange instead of two, two, 2 (W - 1) and one.
+    int alltoall(int rank, const void* src, void* dst, size_t bytes_per_peer, hipStream_t s, bool chained = false);
     int allreduce_sum(int rank, double* vals, int n, hipStream_t s);
     void abort();                       // a rank failed outside a collective: release everybody waiting in one
     void reset();                       // before a new collective call sequence (all ranks idle)
@@ -50,14 +55,18 @@ public:
     bool use_kernel = false;            // pulls as one gather kernel reading the peers' buffers directly (else hipMemcpyPeerAsync calls)
     bool distinct = false;              // at least two ranks sit on different devices (bytes really cross the links)
     unsigned long long barriers = 0;    // rendezvous passed by rank 0 (diagnostics: smo_comm_get key 4)
+    std::vector<double> wait_ms;        // per rank: host time spent waiting in rendezvous so far
 
 private:
-    int barrier();                      // SMO_OK, or SMO_ERR_STATE when a rank has failed
+    int barrier(int rank);              // SMO_OK, or SMO_ERR_STATE when a rank has failed
     alignas(64) std::atomic<int> waiting{0};
     alignas(64) std::atomic<unsigned long> generation{0};
     alignas(64) std::atomic<bool> failed{false};
-    std::vector<const void*> pub_src;
-    std::vector<void*> pub_dst;
+    // published per exchange in one of TWO slots (exchange count of the rank, parity): after a chained exchange a rank may already publish
+    // its next exchange while a slower peer still reads this one; it cannot get further ahead than that (the next rendezvous holds it)
+    std::vector<const void*> pub_src;   // [2][W]
+    std::vector<void*> pub_dst;         // [2][W]
+    std::vector<unsigned long> seq;     // [W * 8]: exchanges started by each rank (one cache line apart)
     std::vector<hipEvent_t> ev_ready, ev_pulled;
     std::vector<double> red;            // [rank][64]
 };
@@ -69,10 +78,12 @@ public:
     bool ready() const { return nccl_ != nullptr || a2a_ != nullptr || peers_ != nullptr || null_; }
     int set_peers(int rank, PeerGroup* g);
     bool is_rccl() const { return nccl_ != nullptr; }
+    double wait_ms() const { return peers_ ? peers_->wait_ms[(size_t)rank * 8] : 0.0; }      // host time this rank has waited for its peers (multi-device contexts)
     int init_rccl(int rank, int world, const void* unique_id);
     int set_transport(int rank, int world, smo_alltoall_fn a2a, smo_allreduce_fn ared, void* user);
     // every rank sends `bytes_per_peer` bytes at src + p*bytes_per_peer to rank p and receives rank p's block at dst + p*bytes_per_peer
-    int alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s);
+    // (chained: see PeerGroup::alltoall; the other transports ignore it)
+    int alltoall(const void* src, void* dst, size_t bytes_per_peer, hipStream_t s, bool chained = false);
     // sum over the ranks of n doubles (host values in and out); synchronises `s`.  `dev_scratch`: >= n doubles of device memory
     int allreduce_sum(double* vals, int n, hipStream_t s, double* dev_scratch);
     static int unique_id(void* out128);

@@ -66,10 +66,17 @@ void Timing::reset() {
     for (auto& n : seen) n = 0;
 }
 void Timing::begin(int k, hipStream_t s) {
-    static const bool env_pre = [] { const char* e = getenv("SMO_TIMING_PRE_MARKER"); return !(e && atoi(e) == 0); }();
-    Pending p{k, get(), get(), nullptr};
-    if (pre_marker && env_pre) { p.pre = get(); (void)hipEventRecord(p.pre, s); }
+    Pending p{k, get(), get()};
     (void)hipEventRecord(p.a, s);
+    pend.push_back(p);
+}
+bool Timing::stamping() const {
+    static const bool env_on = [] { const char* e = getenv("SMO_TIMING_STAMP"); return !(e && atoi(e) == 0); }();
+    return stamp && env_on;
+}
+void Timing::begin_stamped(int k, hipEvent_t* a, hipEvent_t* b) {
+    Pending p{k, get(), get()};
+    *a = p.a; *b = p.b;
     pend.push_back(p);
 }
 void Timing::end(int k, hipStream_t s) {
@@ -85,7 +92,6 @@ int Timing::flush() {
         }
         free_ev.push_back(p.a);
         free_ev.push_back(p.b);
-        if (p.pre) free_ev.push_back(p.pre);
     }
     pend.clear();
     return SMO_OK;

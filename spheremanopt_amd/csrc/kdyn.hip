@@ -24,6 +24,7 @@
 //             curl) for the next step, on the same tile
 //   nu      : the adjoint's second product is summed over the steps on the grid side (x-transformed) and transformed once
 #include <algorithm>
+#include <chrono>
 
 #include "comm.hpp"
 #include "fft_lds.hpp"
@@ -144,10 +145,27 @@ template <bool NTL> __device__ __forceinline__ cplx ld_pair(const double* q) {  
 // ---------------------------------------------------------------------------------------------------------
 enum { ZI_PLAIN = 0, ZI_CURL = 1, ZI_SCALE = 2 };     // load the field | load i k x field | load dt*alpha(k)*field
 
+// Tile of the z passes: one row per transform (lanes run along a row: the global accesses are the contiguous ones), element (b, pos) at
+// b * L + swz(pos).  Row-major as it stands, the stride-4 stores of the first two Stockham stages put the 8 lanes of a ds_write_b128 group on
+// 2 (first stage) / 4 (second) of the 8 sixteen-byte slots: 32-38 % of the LDS-active cycles of the update kernels were bank conflicts
+// (profiles/r03_kdyn*_sq_counters.txt).  SMO_Z_SWZ = 1: pos ^ ((pos >> 2) & 7), 2: pos ^ ((pos >> 3) & 7) — a permutation inside every aligned
+// block of 8 positions (needs L % 8 == 0) that spreads those stores over all slots (tools/lds_conflict_model.py rules: array cycles per tile
+// 620 -> 416 / 444 at G = 192, 1440 -> 1152 / 1008 at G = 384; the contiguous stage reads pay a little instead).
+#ifndef SMO_Z_SWZ
+#define SMO_Z_SWZ 0
+#endif
+template <int L> struct ZIx {
+    static constexpr int SWZ = (L % 8 == 0) ? SMO_Z_SWZ : 0;
+    __device__ __forceinline__ int operator()(int b, int pos) const {
+        return b * L + (SWZ == 1 ? (pos ^ ((pos >> 2) & 7)) : SWZ == 2 ? (pos ^ ((pos >> 3) & 7)) : pos);
+    }
+};
+
 template <int L, int MODE, int NBT, int NT>
 __global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, cplx* __restrict__ out, const cplx* __restrict__ tw_g,
                                                    Geom g) {
     constexpr int NB = 3 * NBT;
+    constexpr ZIx<L> ix{};
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, 
         for (int t = tid; t < NB * g.m; t += NT) {
             const int b = t / g.m, idx = t - b * g.m, tt = b / 3, c = b - 3 * tt, rt = rt0 + tt;
             const int pos = (idx <= g.kmax) ? idx : idx + (g.G - g.m);
-            buf[b * L + pos] = (rt < nrt) ? in[c * cs + (size_t)rt * g.m + idx] : mk(0, 0);
+            buf[ix(b, pos)] = (rt < nrt) ? in[c * cs + (size_t)rt * g.m + idx] : mk(0, 0);
         }
         __syncthreads();
         auto ldc = [&](int b, int pos) -> cplx {
@@ -192,13 +210,13 @@ __global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, 
             const int ixl = rt / g.m, iy = rt - ixl * g.m;
             const double k[3] = {(double)(g.ix0 + ixl), wavenumber(iy, g), wavenumber(idx, g)};
             const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            const cplx v1 = buf[(tt * 3 + c1) * L + pos], v2 = buf[(tt * 3 + c2) * L + pos];
+            const cplx v1 = buf[ix(tt * 3 + c1, pos)], v2 = buf[ix(tt * 3 + c2, pos)];
             return mul_i(mk(k[c1] * v2.re - k[c2] * v1.re, k[c1] * v2.im - k[c2] * v1.im));      // (i k x V)_c
         };
-        fft_inplace<L, true, NB, NT, false, true, false>(buf, L, tw, tid, ldc, stN);
+        fft_inplace_ix<L, true, NB, NT, false, true, false>(buf, ix, tw, tid, ldc, stN);
         return;
     }
-    fft_inplace<L, true, NB, NT, false, false, false>(buf, L, tw, tid, ld0, stN);
+    fft_inplace_ix<L, true, NB, NT, false, false, false>(buf, ix, tw, tid, ld0, stN);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
                                                    const cplx* snap, const cplx* __restrict__ tw_g, Geom g, double scale, int integrated,
                                                    cplx* next_out /* may alias inA */) {
     constexpr int NB = 3 * NBT;
+    constexpr ZIx<L> ix{};
     __shared__ cplx buf[NB * L];
     __shared__ cplx tw[L];
     const int tid = threadIdx.x;
@@ -254,10 +273,10 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
             const int idx = wrap_pos(pos, g);
             if (rt < nrt && idx >= 0) out0[c * cs + (size_t)rt * g.m + idx] = scale * v;
         };
-        fft_inplace<L, false, NB, NT, false, false, false>(buf, L, tw, tid, ld0, stN);
+        fft_inplace_ix<L, false, NB, NT, false, false, false>(buf, ix, tw, tid, ld0, stN);
         return;
     }
-    fft_inplace<L, false, NB, NT, false, false, true>(buf, L, tw, tid, ld0, [&](int b, int pos, cplx v) { buf[b * L + pos] = v; });
+    fft_inplace_ix<L, false, NB, NT, false, false, true>(buf, ix, tw, tid, ld0, [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
     __syncthreads();
     // per-mode update: thread <-> (tt, iz), iz fastest
     for (int t = tid; t < NBT * g.m; t += NT) {
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
         const double D = k2 / g.Rm, alpha = 1.0 / g.dt + 0.5 * D, beta = 1.0 / g.dt - 0.5 * D;
         const size_t e = (size_t)rt * g.m + iz;
         cplx E[3], V0[3], V1[3];
-        for (int c = 0; c < 3; ++c) E[c] = scale * buf[(tt * 3 + c) * L + pos];
+        for (int c = 0; c < 3; ++c) E[c] = scale * buf[ix(tt * 3 + c, pos)];
         if (MODE == ZF_NU) {
             if (k2 == 0.0) {
                 for (int c = 0; c < 3; ++c) V1[c] = mk(0, 0);
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
         if (NEXT != NX_NONE) {                          // the new state (or its curl) replaces the spectrum in the tile
             for (int c = 0; c < 3; ++c) {
                 const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                buf[(tt * 3 + c) * L + pos] = (NEXT == NX_PLAIN) ? V1[c]
+                buf[ix(tt * 3 + c, pos)] = (NEXT == NX_PLAIN) ? V1[c]
                     : mul_i(mk(k[c1] * V1[c2].re - k[c2] * V1[c1].re, k[c1] * V1[c2].im - k[c2] * V1[c1].im));
             }
         }
@@ -311,10 +330,10 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
         const int gap = g.G - g.m;                      // zero padding between the positive and the negative wavenumbers
         for (int t = tid; t < NB * gap; t += NT) {
             const int b = t / gap, q = t - b * gap;
-            buf[b * L + g.kmax + 1 + q] = mk(0, 0);
+            buf[ix(b, g.kmax + 1 + q)] = mk(0, 0);
         }
         __syncthreads();
-        fft_inplace<L, true, NB, NT, false, true, false>(buf, L, tw, tid, [&](int b, int pos) { return buf[b * L + pos]; },
+        fft_inplace_ix<L, true, NB, NT, false, true, false>(buf, ix, tw, tid, [&](int b, int pos) { return buf[ix(b, pos)]; },
                                                          [&](int b, int pos, cplx v) {
                                                              const int c = b % 3, tt = b / 3, rt = rt0 + tt;
                                                              if (rt < nrt) next_out[zs_off(c, rt, pos, g)] = v;
@@ -1041,6 +1060,7 @@ public:
         // 240 -> 205 us for the fused adjoint x pass at 128^3.  SMO_KD_TYPAD (elements, a multiple of 8) overrides it for tuning.
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
+        { const char* e = getenv("SMO_PEER_CHAINED"); chain_ok = !(e && atoi(e) == 0); }
         if (any_size) {
             fuse_next = false;                               // the run-time-length update kernel has no fused next pass
             plan = any_plan(3 * N / 2);
@@ -1243,10 +1263,10 @@ public:
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
             const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
-            ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream);
-            if (mode == ZI_PLAIN) hipLaunchKernelGGL((kd_z_inverse<L, ZI_PLAIN, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
-            else if (mode == ZI_CURL) hipLaunchKernelGGL((kd_z_inverse<L, ZI_CURL, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
-            else hipLaunchKernelGGL((kd_z_inverse<L, ZI_SCALE, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
+            ScopedTimer t(timing, mode == ZI_CURL ? k_zic : (mode == ZI_PLAIN ? k_zi : k_misc), stream, true);
+            if (mode == ZI_PLAIN) SMO_LAUNCH_T(t, (kd_z_inverse<L, ZI_PLAIN, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
+            else if (mode == ZI_CURL) SMO_LAUNCH_T(t, (kd_z_inverse<L, ZI_CURL, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
+            else SMO_LAUNCH_T(t, (kd_z_inverse<L, ZI_SCALE, S::ZNBT, S::ZNT>), dim3(nwg), dim3(S::ZNT), 0, stream, in, out, d_tw, g);
             return SMO_OK;
         });
     }
@@ -1268,12 +1288,12 @@ public:
         return with_L([&](auto l) {
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
-            ScopedTimer t(timing, inv ? k_yi : k_yf, stream);
+            ScopedTimer t(timing, inv ? k_yi : k_yf, stream, true);
             auto launch = [&](auto zt) {
                 constexpr int ZT = decltype(zt)::value;
                 const int nwg = 3 * g.a * ((g.Gzl + ZT - 1) / ZT);
-                if (inv) hipLaunchKernelGGL((kd_y_pass<L, true, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, ty, d_tw, q);
-                else hipLaunchKernelGGL((kd_y_pass<L, false, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ty, ex, d_tw, q);
+                if (inv) SMO_LAUNCH_T(t, (kd_y_pass<L, true, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ex, ty, d_tw, q);
+                else SMO_LAUNCH_T(t, (kd_y_pass<L, false, ZT, S::YNT>), dim3(nwg), dim3(S::YNT), 0, stream, (const cplx*)ty, ex, d_tw, q);
             };
             // thin slabs: halve the z tile when that avoids a mostly empty last tile (e.g. 128^3 on 8 GPUs: 24 local planes)
             if (g.Gzl % S::YZT != 0 && g.Gzl % (S::YZT / 2) == 0) launch(std::integral_constant<int, S::YZT / 2>());
@@ -1308,16 +1328,16 @@ public:
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
             const int kc = mode == X_FUSED_FWD ? k_xf : (mode == X_FUSED_ADJ ? k_xa : k_misc);
-            ScopedTimer t(timing, kc, stream);
+            ScopedTimer t(timing, kc, stream, true);
             switch (mode) {
-                case X_TO_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                case X_FROM_GRID: hipLaunchKernelGGL((kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_TO_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FROM_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 default:
                     // adjoint: the field groups one after the other through the tile buffer (tiles as wide as the forward pass's), unless
                     // SMO_KD_ADJ_SEQ=0 asks for both at once in half-width tiles (round 1's kernel, kept for comparison)
-                    if (adj_seq) hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XSNT, 8 / S::XT>), tiles(S::XT), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
-                    else hipLaunchKernelGGL((kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    if (adj_seq) SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XSNT, 8 / S::XT>), tiles(S::XT), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    else SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q);
                     break;
             }
             return SMO_OK;
@@ -1340,10 +1360,10 @@ public:
             constexpr int L = decltype(l)::value;
             using S = Shape<L>;
             const int k = mode == ZF_FWD_UPDATE ? k_zfu : (mode == ZF_ADJ_UPDATE ? k_zfa : k_misc);
-            ScopedTimer t(timing, k, stream);
+            ScopedTimer t(timing, k, stream, true);
             const int nwg = (g.al * g.m + S::ZNBT - 1) / S::ZNBT;
             const dim3 grid(nwg), block(S::ZNT);
-#define SMO_ZF(MODE_, NEXT_) hipLaunchKernelGGL((kd_z_forward<L, MODE_, NEXT_, S::ZNBT, S::ZNT>), grid, block, 0, stream, (const cplx*)zs, out0, state0, snp, d_tw, g, scale, integ, zs)
+#define SMO_ZF(MODE_, NEXT_) SMO_LAUNCH_T(t, (kd_z_forward<L, MODE_, NEXT_, S::ZNBT, S::ZNT>), grid, block, 0, stream, (const cplx*)zs, out0, state0, snp, d_tw, g, scale, integ, zs)
             if (mode == ZF_PLAIN) SMO_ZF(ZF_PLAIN, NX_NONE);
             else if (mode == ZF_NU) SMO_ZF(ZF_NU, NX_NONE);
             else if (mode == ZF_FWD_UPDATE) { if (next == NX_PLAIN) SMO_ZF(ZF_FWD_UPDATE, NX_PLAIN); else SMO_ZF(ZF_FWD_UPDATE, NX_NONE); }
@@ -1472,14 +1492,17 @@ public:
         for (auto* v : {&ev_in, &ev_ph, &ev_out}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     }
     // all-to-all of chunk k, nf field groups: z side -> y side (to_y) or back.  Peer blocks are contiguous: [chunk][peer][nf*tzc]
-    int exchange(bool to_y, int nf, int k, hipStream_t s) {
+    // chained: an exchange of the time loop (stage()), whose send buffer is next written by the pull of the exchange that follows it on the
+    // same stream — the multi-device transport then skips its second rendezvous (comm.hpp).  SMO_PEER_CHAINED=0 keeps the full protocol.
+    bool chain_ok = true;
+    int exchange(bool to_y, int nf, int k, hipStream_t s, bool chained = false) {
         if (!exchanging()) return SMO_OK;
         const size_t off = (size_t)k * (size_t)cfg.world * 2 * tzc;
         const cplx* src = (to_y ? zs : ys) + off;
         cplx* dst = (to_y ? ys : zs) + off;
         if (!to_y) zs_ready_fwd = zs_ready_adj = -1;
         ScopedTimer t(timing, k_ex, s);
-        return comm.alltoall(src, dst, (size_t)nf * tzc * sizeof(cplx), s);
+        return comm.alltoall(src, dst, (size_t)nf * tzc * sizeof(cplx), s, chained && chain_ok);
     }
     enum { ST_FWD = 0, ST_ADJ = 1 };
     int grid_phase(int code, int idx, int k) { return code == ST_FWD ? fwd_B(idx, k) : adj_B(idx, k); }
@@ -1488,14 +1511,14 @@ public:
     // exchange of chunk k overlaps the kernels of chunk k+1.
     int stage(int code, int idx, int nf_in, int nf_out) {
         if (!exchanging() || K == 1) {
-            SMO_TRY(exchange(true, nf_in, 0, stream));
+            SMO_TRY(exchange(true, nf_in, 0, stream, true));
             SMO_TRY(grid_phase(code, idx, 0));
-            return exchange(false, nf_out, 0, stream);
+            return exchange(false, nf_out, 0, stream, true);
         }
         SMO_HIP(hipEventRecord(ev_main, stream));
         SMO_HIP(hipStreamWaitEvent(cstream, ev_main, 0));
         for (int k = 0; k < K; ++k) {
-            SMO_TRY(exchange(true, nf_in, k, cstream));
+            SMO_TRY(exchange(true, nf_in, k, cstream, true));
             SMO_HIP(hipEventRecord(ev_in[k], cstream));
         }
         for (int k = 0; k < K; ++k) {
@@ -1503,7 +1526,7 @@ public:
             SMO_TRY(grid_phase(code, idx, k));
             SMO_HIP(hipEventRecord(ev_ph[k], stream));
             SMO_HIP(hipStreamWaitEvent(cstream, ev_ph[k], 0));
-            SMO_TRY(exchange(false, nf_out, k, cstream));
+            SMO_TRY(exchange(false, nf_out, k, cstream, true));
             SMO_HIP(hipEventRecord(ev_out[k], cstream));
         }
         for (int k = 0; k < K; ++k) SMO_HIP(hipStreamWaitEvent(stream, ev_out[k], 0));
@@ -1690,9 +1713,14 @@ public:
         hipLaunchKernelGGL(kd_energy, dim3(NPART), dim3(256), 0, stream, snap(N), d_part + (integ ? (size_t)N * NPART : 0), g);
         return SMO_OK;
     }
+    // host time this rank spent ISSUING the last forward + adjoint solve: from the entry of the call to the point where everything is
+    // enqueued, minus the time spent waiting for the other ranks in host rendezvous (smo_get key 4, milliseconds)
+    double issue_ms_fwd = 0.0, issue_ms_adj = 0.0;
+    static double now_ms() { return 1e-6 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int forward_dev(const double* const* X, double* J) override {
         SMO_TRY(loop_ok("smo_forward"));
         have_forward = false;
+        const double t_in = now_ms(), w_in = comm.wait_ms();
         const int N = cfg.n_iters;
         const bool integ = cfg.cost == SMO_COST_INTEGRATED;
         if (use_graph()) {
@@ -1702,6 +1730,7 @@ public:
         } else {
             SMO_TRY(fwd_enqueue(X[0], X[1]));
         }
+        issue_ms_fwd = (now_ms() - t_in) - (comm.wait_ms() - w_in);
         scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
         const size_t rows = integ ? (size_t)N + 1 : 1;
         SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, rows * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1740,6 +1769,7 @@ public:
     }
     int adjoint_dev(const double* const*, int adjoint_type, double* const* grad) override {
         SMO_TRY(loop_ok("smo_adjoint"));
+        const double t_in = now_ms(), w_in = comm.wait_ms();
         if (use_graph()) {
             SMO_TRY(graph_buffers());
             const int a = adjoint_type == SMO_ADJ_CONTINUOUS ? 1 : 0;
@@ -1748,6 +1778,7 @@ public:
         } else {
             SMO_TRY(adj_enqueue(adjoint_type, grad[0], grad[1]));
         }
+        issue_ms_adj = (now_ms() - t_in) - (comm.wait_ms() - w_in);
         SMO_HIP(hipGetLastError());
         SMO_HIP(hipStreamSynchronize(stream));
         if (cstream) SMO_HIP(hipStreamSynchronize(cstream));
@@ -1756,8 +1787,8 @@ public:
 
     int inner_dev(const double* x, const double* y, double* out) override {       // <x,y>; slabs without a communicator: this slab's share
         {
-            ScopedTimer t(timing, k_dot, stream);
-            hipLaunchKernelGGL(kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
+            ScopedTimer t(timing, k_dot, stream, true);
+            SMO_LAUNCH_T(t, kd_dot, dim3(NPART), dim3(256), 0, stream, x, y, d_part, n_grid);
         }
         SMO_HIP(hipGetLastError());
         double s = 0.0;
@@ -1771,6 +1802,7 @@ public:
         if (key == 0) return (double)ck;
         if (key == 2) return (double)graph_replays;
         if (key == 3) return (double)g.tyl;
+        if (key == 4) return issue_ms_fwd + issue_ms_adj;
         return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 

@@ -11,6 +11,7 @@
 //     and as many event operations per step pair against 0.6 ms of kernels at 256^3 / 8);
 //   * scatters X to / gathers grad J from the devices slab by slab (strided 2-D copies: z is the fastest axis and the one that is split).
 // A failing rank releases the others (PeerGroup::abort): the call returns its error instead of hanging.
+#include <algorithm>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -242,7 +243,11 @@ public:
         (void)hipSetDevice(cur);                           // the caller's current device is not ours to change
         return rc;
     }
-    double info(int key) const override { return r.empty() ? 0.0 : r[0]->info(key); }
+    double info(int key) const override {
+        if (r.empty()) return 0.0;
+        if (key == 4) { double m = 0.0; for (auto& x : r) m = std::max(m, x->info(4)); return m; }      // host issue time: the slowest worker
+        return r[0]->info(key);
+    }
     double comm_info(int key) const override {
         if (key == 2) return 0.0;                          // no RCCL communicator here
         if (key == 3) return grp ? (grp->use_kernel ? 2.0 : 1.0) : 0.0;      // transposes: 2 = gather kernel, 1 = hipMemcpyPeerAsync calls

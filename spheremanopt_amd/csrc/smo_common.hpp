@@ -2,6 +2,7 @@
 // HIP-event kernel timing.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -89,11 +90,13 @@ public:
     bool on = false;
     unsigned long long mask = ~0ull;  // classes whose launches are timed (bit k = class k): keeps the event overhead out of the other launches
     int stride = 1;                   // of a selected class, every stride-th launch is timed (smo_timing_stride): a uniform sample at 1/stride of the event cost
-    // A start event recorded straight behind an UN-timed kernel reads early: the queue's marker packet is picked up while that kernel's last
-    // workgroups still run, so the interval includes the predecessor's tail (round 3: the every-8th-launch sample read 2.4-4.6 % above the
-    // every-launch average, where each start event follows the previous launch's END event).  pre_marker = true records one more event
-    // ahead of the start event, which absorbs that tail: begin = [pre][a], the interval is a..b as before.  SMO_TIMING_PRE_MARKER=0 disables.
-    bool pre_marker = true;
+    // How a timed launch gets its interval.  stamp = true (default; SMO_TIMING_STAMP=0 disables): the launch goes through
+    // hipExtLaunchKernelGGL(..., startEvent, stopEvent), whose events carry the dispatch's OWN begin / end timestamps — the quantity
+    // rocprofv3 --kernel-trace reports — and put no marker packet into the queue.  stamp = false (and every class that is not a single
+    // kernel launch, e.g. the exchanges): hipEventRecord before and after, i.e. two marker packets; a start marker recorded straight behind
+    // an un-timed kernel is processed while that kernel's last workgroups still run, so such an interval includes the predecessor's tail
+    // (round 3: the every-8th-launch sample read 2.4-4.6 % above the every-launch average).
+    bool stamp = true;
     std::vector<long long> seen;      // launches of each class since the last reset, timed or not
     std::vector<TimingClass> cls;
     int add_class(const char* name, double bytes, double hbm = -1.0) {
@@ -104,10 +107,12 @@ public:
     void reset();
     void begin(int k, hipStream_t s);
     void end(int k, hipStream_t s);
+    bool stamping() const;            // stamp && !SMO_TIMING_STAMP=0
+    void begin_stamped(int k, hipEvent_t* a, hipEvent_t* b);      // events for hipExtLaunchKernelGGL; nothing is recorded here
     int flush();                      // resolve pending event pairs (after a stream sync)
     ~Timing();
 private:
-    struct Pending { int k; hipEvent_t a, b, pre; };
+    struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pend;
     std::vector<hipEvent_t> free_ev;
     hipEvent_t get();
@@ -116,12 +121,22 @@ private:
 struct ScopedTimer {
     Timing& t; int k; hipStream_t s;
     bool active;
-    ScopedTimer(Timing& t_, int k_, hipStream_t s_) : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && k_ < 64 && ((t_.mask >> k_) & 1ull)) {
+    bool stamped = false;             // the launch itself carries the events (SMO_LAUNCH_T): no markers
+    hipEvent_t ea = nullptr, eb = nullptr;
+    ScopedTimer(Timing& t_, int k_, hipStream_t s_, bool single_kernel = false)
+        : t(t_), k(k_), s(s_), active(t_.on && k_ >= 0 && k_ < 64 && ((t_.mask >> k_) & 1ull)) {
         if (active && t.stride > 1) active = (t.seen[k]++ % t.stride) == 0;
-        if (active) t.begin(k, s);
+        if (active && single_kernel && t.stamping()) { stamped = true; t.begin_stamped(k, &ea, &eb); }
+        else if (active) t.begin(k, s);
     }
-    ~ScopedTimer() { if (active) t.end(k, s); }
+    ~ScopedTimer() { if (active && !stamped) t.end(k, s); }
 };
+// launch `kernel` under ScopedTimer `tm` (constructed with single_kernel = true): with the dispatch's own timestamps when it is a timed launch
+#define SMO_LAUNCH_T(tm, kernel, grid, block, shmem, stream, ...)                                                                   \
+    do {                                                                                                                            \
+        if ((tm).stamped) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (tm).ea, (tm).eb, 0, __VA_ARGS__);               \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                                  \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // context base
