@@ -25,6 +25,7 @@
 //   nu      : the adjoint's second product is summed over the steps on the grid side (x-transformed) and transformed once
 #include <algorithm>
 #include <chrono>
+#include <type_traits>
 
 #include "comm.hpp"
 #include "fft_lds.hpp"
@@ -167,10 +168,21 @@ __global__ __launch_bounds__(NT) void kd_z_inverse(const cplx* __restrict__ in, 
     constexpr int NB = 3 * NBT;
     constexpr ZIx<L> ix{};
     __shared__ cplx buf[NB * L];
-    __shared__ cplx tw[L];
+#ifndef SMO_Z_HALF_TW_MIN_L
+#define SMO_Z_HALF_TW_MIN_L 200
+#endif
+    // half twiddle table from SMO_Z_HALF_TW_MIN_L on: 24.6 -> 21.5 KB at G = 384, seven workgroups per CU instead of six (256^3: z_inverse<curl>
+    // 256.8 -> 223.4 us, fwd_update 426.2 -> 418.3, adj_update unchanged)
+    constexpr bool HALF = (L >= SMO_Z_HALF_TW_MIN_L) && (L % 2 == 0);
+    constexpr int NTW = HALF ? L / 2 : L;
+    __shared__ cplx tw_s[NTW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    for (int i = tid; i < NTW; i += NT) tw_s[i] = tw_g[i];
     __syncthreads();
+    using TWT = typename std::conditional<HALF, HalfTwiddles, const cplx*>::type;
+    TWT tw;
+    if constexpr (HALF) tw = HalfTwiddles{tw_s, L / 2};
+    else tw = tw_s;
     const int nrt = g.al * g.m;
     const int rt0 = blockIdx.x * NBT;
     const size_t cs = (size_t)nrt * g.m;
@@ -254,10 +266,21 @@ __global__ __launch_bounds__(NT) void kd_z_forward(const cplx* inA, cplx* out0, 
     constexpr int NB = 3 * NBT;
     constexpr ZIx<L> ix{};
     __shared__ cplx buf[NB * L];
-    __shared__ cplx tw[L];
+#ifndef SMO_Z_HALF_TW_MIN_L
+#define SMO_Z_HALF_TW_MIN_L 200
+#endif
+    // half twiddle table from SMO_Z_HALF_TW_MIN_L on: 24.6 -> 21.5 KB at G = 384, seven workgroups per CU instead of six (256^3: z_inverse<curl>
+    // 256.8 -> 223.4 us, fwd_update 426.2 -> 418.3, adj_update unchanged)
+    constexpr bool HALF = (L >= SMO_Z_HALF_TW_MIN_L) && (L % 2 == 0);
+    constexpr int NTW = HALF ? L / 2 : L;
+    __shared__ cplx tw_s[NTW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    for (int i = tid; i < NTW; i += NT) tw_s[i] = tw_g[i];
     __syncthreads();
+    using TWT = typename std::conditional<HALF, HalfTwiddles, const cplx*>::type;
+    TWT tw;
+    if constexpr (HALF) tw = HalfTwiddles{tw_s, L / 2};
+    else tw = tw_s;
     const int nrt = g.al * g.m;
     const int rt0 = blockIdx.x * NBT;
     const size_t cs = (size_t)nrt * g.m;
@@ -352,10 +375,22 @@ __global__ __launch_bounds__(NT) void kd_y_pass(const cplx* __restrict__ in, cpl
     // the z-block-major Ty addressing below (trow, tys = 8) is written for tiles that lie inside one block of 8 z columns
     static_assert(ZT <= 8 && 8 % ZT == 0, "kd_y_pass: SMO_Y_ZT must divide 8 (z-block-major Ty)");
     __shared__ cplx buf[ZT * L];
-    __shared__ cplx tw[L];
+    // half twiddle table (the other half is its negative) from SMO_Y_HALF_TW_MIN_L on: at G = 384 the 8-column tile + the full table is 55.3 KB — two
+    // workgroups per CU, 2.96 would fit —, with half a table 52.2 KB: three.  Round 4, 256^3, same box: y<inv> 310.0 -> 299.4 us, y<fwd> 285.5 -> 270.9;
+    // at G = 192 (five -> six workgroups per CU) nothing moves, so the full table stays there (and the results of the smaller grids as they were)
+#ifndef SMO_Y_HALF_TW_MIN_L
+#define SMO_Y_HALF_TW_MIN_L 200
+#endif
+    constexpr bool HALF = (L >= SMO_Y_HALF_TW_MIN_L) && (L % 2 == 0);
+    constexpr int NTW = HALF ? L / 2 : L;
+    __shared__ cplx tw_s[NTW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += NT) tw[i] = tw_g[i];
+    for (int i = tid; i < NTW; i += NT) tw_s[i] = tw_g[i];
     __syncthreads();
+    using TWT = typename std::conditional<HALF, HalfTwiddles, const cplx*>::type;
+    TWT tw;
+    if constexpr (HALF) tw = HalfTwiddles{tw_s, L / 2};
+    else tw = tw_s;
     const int ntile = (g.Gzl + ZT - 1) / ZT;
     int c, kx, z0;
     if (g.tyl && g.ykx) {                       // consecutive workgroups: consecutive kx of one (c, z tile) — adjacent blocks of Ty
@@ -437,7 +472,7 @@ constexpr bool only_2_and_3(int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 
 
 template <int L, int MODE, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
-                                       cplx* buf, const TW tw, const size_t i0, const int tid) {
+                                       cplx* buf, const TW tw, const size_t i0, const int tid, const XOrigin* xo_in = nullptr) {
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
@@ -446,7 +481,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
     // offset in Ty of (component c, mode kx, line pair p of this tile): tiles of up to 8 points lie inside one z block of either layout
-    const XOrigin xo = x_origin(i0, g);
+    const XOrigin xo = xo_in ? *xo_in : x_origin(i0, g);
     auto spec_off = [&](int c, int kx, int p) -> size_t {
         if constexpr (T <= 8) return xo.base + c * xo.cs + kx * xo.ks + 2 * p;
         else return ty_off(c, kx, i0 + 2 * p, g);
@@ -651,7 +686,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 // ---------------------------------------------------------------------------------------------------------
 template <int L, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __restrict__ gridU, const Geom& g, cplx* buf, const TW tw,
-                                               const size_t i0, const int tid) {
+                                               const size_t i0, const int tid, const XOrigin* xo_in = nullptr) {
     constexpr int HP = T / 2, NB = 3 * HP, S3 = L / 3;
     constexpr XLayout<L, NB, true> ix{};
     constexpr int NITEM = S3 * 3 * HP;                         // stored modes of one field group = items of the staging / split loops
@@ -662,7 +697,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
     auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
     static_assert(T <= 8, "a tile lies inside one z block of Ty");
-    const XOrigin xo = x_origin(i0, g);
+    const XOrigin xo = xo_in ? *xo_in : x_origin(i0, g);
     auto spec_off = [&](int c, int kx, int p) -> size_t { return xo.base + c * xo.cs + kx * xo.ks + 2 * p; };
 
     // SMO_X_SEQ_PREFETCH = n: the first n (of SCNT) spectral items of B_f per thread are requested before the last forward stage of F1 instead
@@ -848,7 +883,8 @@ template <int L, int MODE, int T, int NT, int PAIRED = 0>         // PAIRED = ti
 #ifndef SMO_X_SEQ_NT
 #define SMO_X_SEQ_NT SMO_X_FWD_NT      // threads of the sequential adjoint pass (experiments: 320, 384)
 #endif
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? SMO_X_SEQ_WAVES : SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
+// (a sequential adjoint tile with more than one middle-section item per thread — SMO_X_SEQ_T_BIG = 8 — is built for two waves per SIMD: 256 VGPRs)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? ((T / 2) * (L / 3) > NT ? 2 : SMO_X_SEQ_WAVES) : SMO_X_WAVES))) void kd_x_pass(XSpec sp, const double* __restrict__ gridU, double* gridOut,
                                                 const cplx* __restrict__ tw_g, Geom g) {
     constexpr int NB = ((MODE == X_FUSED_ADJ) ? 2 : 1) * 3 * (T / 2);
     __shared__ cplx buf[XLayout<L, NB, (MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ || MODE == X_FUSED_ADJ_SEQ)>::ELEMS];
@@ -886,6 +922,70 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FU
     } else {
         if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid);
         else x_tile<L, MODE, T, NT>(sp, gridU, gridOut, g, buf, (const cplx*)tw_s, i0, tid);
+    }
+}
+
+// The fused x passes as PERSISTENT workgroups with a DYNAMIC tile queue (round 4; SMO_KD_X_DYN=1).  gridDim.x = what fits the chip at once
+// (occupancy x 256 CUs); a workgroup loads the twiddle table once and then takes tiles from its XCD's queue — one atomicAdd per tile — until the
+// queue is empty.  Round 2's static form (tile = b, b + grid, ...) lost 27-37 % to imbalance; a queue has none.  queue[0..7] = next tile
+// group of XCD x (workgroup b sits on XCD b % 8, as the PAIRED mapping of kd_x_pass assumes), tiles dealt to the XCDs in groups of P = 8 / T
+// (the tiles of one 128-byte line of the spectra stay on one XCD); queue[8] counts finished workgroups: the last one zeroes the counters for the
+// next launch (same stream: ordered).
+template <int L, int MODE, int T, int NT, int PAIRED>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? SMO_X_SEQ_WAVES : SMO_X_WAVES))) void kd_x_pass_dyn(XSpec sp, const double* __restrict__ gridU,
+                                                const cplx* __restrict__ tw_g, Geom g, unsigned* queue, unsigned ntiles, unsigned stagger) {
+    static_assert(MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ_SEQ, "fused passes only");
+    static_assert(T <= 8, "tiles inside one z block");
+    constexpr int NB = 3 * (T / 2);
+    __shared__ cplx buf[XLayout<L, NB, true>::ELEMS];
+    constexpr bool HALF = (L > 192);
+    constexpr int NTW = HALF ? L / 2 : L;
+    __shared__ cplx tw_s[NTW];
+    __shared__ unsigned s_next;
+    for (int i = threadIdx.x; i < NTW; i += NT) tw_s[i] = tw_g[i];
+    constexpr unsigned P = PAIRED > 1 ? PAIRED : 1;
+    const unsigned xcd = blockIdx.x & 7u;
+    // all workgroups of a persistent grid start together and every tile takes the same time: without a spread they stay in phase (all loading,
+    // then all computing).  `stagger` > 0: workgroup b starts ((b * 2654435761) >> 26) % stagger sleep units (~2 us each at 2 GHz) late.
+    if (stagger) {
+        const unsigned d = ((blockIdx.x * 2654435761u) >> 20) % stagger;
+        for (unsigned i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    // the ticket of the NEXT tile is drawn at the start of the current one: the atomic's round trip (a loaded-memory latency, several us when
+    // the chip streams) overlaps the tile's work instead of standing between two tiles with the whole workgroup waiting
+    unsigned ticket = 0;
+    if (threadIdx.x == 0) ticket = atomicAdd(&queue[xcd], 1u);
+    for (;;) {
+        __syncthreads();                                   // the previous tile's last reads of buf / s_next are done (first pass: the table is in place)
+        if (threadIdx.x == 0) s_next = ticket;
+        __syncthreads();
+        const unsigned q = s_next;
+        const size_t tile = (size_t)(q / P) * (8 * P) + xcd * P + q % P;
+        if (tile >= ntiles) break;                         // uniform: every thread reads the same s_next
+        if (threadIdx.x == 0) ticket = atomicAdd(&queue[xcd], 1u);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                      // per-tile copy of the thread index: keeps thread-derived addresses from being hoisted out of (and kept live across) the loop
+        // z-block-major Ty (the only layout this kernel is launched with): tile -> (z block, y, part of the 128-byte line); every division by a
+        // compile-time constant (G == L), the origin of the tile's spectra without one
+        constexpr unsigned PER = 8 / T;
+        const unsigned line = (unsigned)tile / PER, sub = (unsigned)tile - line * PER;
+        const unsigned zb = line / (unsigned)L, y = line - zb * (unsigned)L;
+        const size_t i0 = (size_t)y * g.Gzl + zb * 8u + sub * T;
+        const XOrigin xo{(size_t)zb * g.a * g.tyk + (size_t)y * 8 + sub * T, (size_t)(g.Gzl >> 3) * g.a * g.tyk, g.tyk};
+        if constexpr (MODE == X_FUSED_ADJ_SEQ) {
+            if constexpr (HALF) x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid, &xo);
+            else x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, (const cplx*)tw_s, i0, tid, &xo);
+        } else {
+            if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, nullptr, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid, &xo);
+            else x_tile<L, MODE, T, NT>(sp, gridU, nullptr, g, buf, (const cplx*)tw_s, i0, tid, &xo);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&queue[8], 1u) == gridDim.x - 1) {   // everybody else has drawn its last (empty) ticket already
+            for (int x = 0; x < 9; ++x) queue[x] = 0u;
+            __threadfence();
+        }
     }
 }
 
@@ -1061,6 +1161,9 @@ public:
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_PEER_CHAINED"); chain_ok = !(e && atoi(e) == 0); }
+        { const char* e = getenv("SMO_KD_X_DYN"); if (e) x_dyn = atoi(e); }
+        { const char* e = getenv("SMO_KD_X_DYN_WG"); if (e) x_dyn_wg = atoi(e); }
+        { const char* e = getenv("SMO_KD_X_DYN_STAGGER"); if (e) x_dyn_stagger = atoi(e); }
         if (any_size) {
             fuse_next = false;                               // the run-time-length update kernel has no fused next pass
             plan = any_plan(3 * N / 2);
@@ -1140,6 +1243,8 @@ public:
         if (W == 1 && !force_exchange) ys = zs;
         else SMO_TRY(pool.alloc(&ys, n_ex));
         SMO_TRY(pool.alloc(&d_red, 8));
+        SMO_TRY(pool.alloc(&d_queue, 16));
+        SMO_HIP(hipMemsetAsync(d_queue, 0, 16 * sizeof(unsigned), stream));
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
@@ -1175,6 +1280,14 @@ public:
 
     // ---- launch helpers -----------------------------------------------------------------------------------------
     template <class F> int with_L(F f) {
+#ifdef SMO_KD_FEW_SIZES              // experimental builds (tools/kernel_resources.sh -DSMO_KD_FEW_SIZES): the two bench grids only, a tenth of the compile time
+        switch (g.G) {
+            case 192: return f(std::integral_constant<int, 192>());
+            case 384: return f(std::integral_constant<int, 384>());
+        }
+        set_error("KDYN: grid %d not in this experimental build", g.G);
+        return SMO_ERR_UNSUPPORTED;
+#else
         switch (g.G) {
             case 12: return f(std::integral_constant<int, 12>());
             case 24: return f(std::integral_constant<int, 24>());
@@ -1207,6 +1320,7 @@ public:
         }
         set_error("KDYN: unsupported grid %d", g.G);
         return SMO_ERR_UNSUPPORTED;
+#endif
     }
     // Workgroup shapes.  FFTs per workgroup are halved for the long transform (G = 384) so the LDS footprint per workgroup
     // (<= 37-49 KB => 3-4 workgroups per CU) and the butterflies per thread stay what they are at G = 192.
@@ -1228,8 +1342,15 @@ public:
         static constexpr int XT = 8 / H, XNT = SMO_X_FWD_NT;
         // sequential adjoint pass: one middle-section item (j, line pair) per thread — it keeps 9 complex grid values of omega per item in
         // registers, a second item per thread spills (G = 480: 320 items, 168 VGPRs + 241 spilled with 256 threads; 320 threads: none)
-        static constexpr int XITEMS = (XT / 2) * (L / 3);
-        static constexpr int XSNT = XITEMS > SMO_X_SEQ_NT ? ((XITEMS + 63) / 64) * 64 : SMO_X_SEQ_NT;
+        // SMO_X_SEQ_T_BIG (experiment, round 4): points per tile of the sequential adjoint pass at G > 192.  4 = half tiles, one item per thread,
+        // three workgroups per CU (40 KB, 168 VGPRs); 8 = whole 128-byte lines, TWO items per thread on 256 threads, two workgroups per CU
+        // (77 KB, built for two waves per SIMD)
+#ifndef SMO_X_SEQ_T_BIG
+#define SMO_X_SEQ_T_BIG 4
+#endif
+        static constexpr int XTS = (L > 192) ? SMO_X_SEQ_T_BIG : XT;
+        static constexpr int XITEMS = (XTS / 2) * (L / 3);
+        static constexpr int XSNT = (XTS != XT) ? SMO_X_SEQ_NT : (XITEMS > SMO_X_SEQ_NT ? ((XITEMS + 63) / 64) * 64 : SMO_X_SEQ_NT);
         static constexpr int XTA = 4 / H, XANT = SMO_X_ADJ_NT;          // adjoint x pass: 12 / 6 FFTs of both field groups; 64 / 32-B runs, tiles grouped per XCD
         static constexpr int XTG = 16 / H, XGNT = 384;         // grid <-> spectrum only (setup / gradient output)
     };
@@ -1332,11 +1453,23 @@ public:
             switch (mode) {
                 case X_TO_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD:
+                    if ((x_dyn == 1 || x_dyn == 2) && q.tyl && plane % 8 == 0) {
+                        const unsigned nt = (unsigned)(plane / S::XT), wg = (unsigned)(x_dyn_wg > 0 ? x_dyn_wg : 4) * 256u;
+                        SMO_LAUNCH_T(t, (kd_x_pass_dyn<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), dim3(std::min(wg, nt)), dim3(S::XNT), 0, stream, sp, grid_in, d_tw, q, d_queue, nt, (unsigned)x_dyn_stagger);
+                        break;
+                    }
+                    SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 default:
+                    if constexpr (S::XTS == S::XT)
+                    if (adj_seq && (x_dyn == 1 || x_dyn == 3) && q.tyl && plane % 8 == 0) {
+                        const unsigned nt = (unsigned)(plane / S::XTS), wg = (unsigned)(x_dyn_wg > 0 ? x_dyn_wg : 3) * 256u;
+                        SMO_LAUNCH_T(t, (kd_x_pass_dyn<L, X_FUSED_ADJ_SEQ, S::XTS, S::XSNT, 8 / S::XTS>), dim3(std::min(wg, nt)), dim3(S::XSNT), 0, stream, sp, grid_in, d_tw, q, d_queue, nt, (unsigned)x_dyn_stagger);
+                        break;
+                    }
                     // adjoint: the field groups one after the other through the tile buffer (tiles as wide as the forward pass's), unless
                     // SMO_KD_ADJ_SEQ=0 asks for both at once in half-width tiles (round 1's kernel, kept for comparison)
-                    if (adj_seq) SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XT, S::XSNT, 8 / S::XT>), tiles(S::XT), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
+                    if (adj_seq) SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XTS, S::XSNT, 8 / S::XTS>), tiles(S::XTS), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
                     else SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ, S::XTA, S::XANT, 8 / S::XTA>), tiles(S::XTA), dim3(S::XANT), 0, stream, sp, grid_in, grid_out, d_tw, q);
                     break;
             }
@@ -1495,6 +1628,9 @@ public:
     // chained: an exchange of the time loop (stage()), whose send buffer is next written by the pull of the exchange that follows it on the
     // same stream — the multi-device transport then skips its second rendezvous (comm.hpp).  SMO_PEER_CHAINED=0 keeps the full protocol.
     bool chain_ok = true;
+    // persistent fused x passes with a dynamic tile queue (kd_x_pass_dyn): SMO_KD_X_DYN = 1 both, 2 forward only, 3 adjoint only; SMO_KD_X_DYN_WG = workgroups per CU
+    int x_dyn = 0, x_dyn_wg = 0, x_dyn_stagger = 0;
+    unsigned* d_queue = nullptr;
     int exchange(bool to_y, int nf, int k, hipStream_t s, bool chained = false) {
         if (!exchanging()) return SMO_OK;
         const size_t off = (size_t)k * (size_t)cfg.world * 2 * tzc;
