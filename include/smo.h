@@ -128,7 +128,8 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes);         /* HBM held by t
  * workgroups that co-operate on one problem (1 = no cluster: batch > 1, fewer than 256 modes, SMO_SHB_CLUSTER=0 or after a time-out);
  * key 3 (KDYN): layout of the y-transformed work fields, 0 = planes [c][kx][y][z], 1 = z-block major [c][z/8][kx][y][z%8];
  * key 4 (KDYN): milliseconds of HOST time the last smo_forward + smo_adjoint spent issuing work (entry of the call until everything is enqueued,
- * minus the waits for other ranks in host rendezvous; a multi-device context reports its slowest worker) — to be set against the kernels' time. */
+ * minus the waits for other ranks in host rendezvous; a multi-device context reports its slowest worker) — to be set against the kernels' time;
+ * key 5 (KDYN): first snapshot index of the dense tail of the checkpoint schedule (every state from there on is kept), -1 = uniform interval. */
 int smo_get(const smo_ctx* ctx, int key, double* value);
 
 /* ---- the three callbacks, host buffers ---------------------------------------------------------------------- */

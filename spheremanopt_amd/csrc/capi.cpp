@@ -93,7 +93,7 @@ int smo_stack_bytes(const smo_ctx* ctx, size_t* bytes) {
 
 int smo_get(const smo_ctx* ctx, int key, double* value) {
     CHECK_CTX(ctx);
-    if (!value || key < 0 || key > 4) { smo::set_error("smo_get: bad argument"); return SMO_ERR_ARG; }
+    if (!value || key < 0 || key > 5) { smo::set_error("smo_get: bad argument"); return SMO_ERR_ARG; }
     *value = ctx->impl->info(key);
     return SMO_OK;
 }

@@ -472,7 +472,7 @@ constexpr bool only_2_and_3(int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 
 
 template <int L, int MODE, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict__ gridU, double* gridOut, const Geom& g,
-                                       cplx* buf, const TW tw, const size_t i0, const int tid, const XOrigin* xo_in = nullptr) {
+                                       cplx* buf, const TW tw, const size_t i0, const int tid) {
     constexpr int NF = (MODE == X_FUSED_ADJ) ? 2 : 1;
     constexpr int HP = T / 2;                       // line pairs
     constexpr int NB = NF * 3 * HP;
@@ -481,7 +481,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
     // b = (f*3 + c)*HP + p
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };      // plane is even, T is even: pairs never straddle the end
     // offset in Ty of (component c, mode kx, line pair p of this tile): tiles of up to 8 points lie inside one z block of either layout
-    const XOrigin xo = xo_in ? *xo_in : x_origin(i0, g);
+    const XOrigin xo = x_origin(i0, g);
     auto spec_off = [&](int c, int kx, int p) -> size_t {
         if constexpr (T <= 8) return xo.base + c * xo.cs + kx * xo.ks + 2 * p;
         else return ty_off(c, kx, i0 + 2 * p, g);
@@ -686,7 +686,7 @@ __device__ __forceinline__ void x_tile(const XSpec& sp, const double* __restrict
 // ---------------------------------------------------------------------------------------------------------
 template <int L, int T, int NT, class TW>
 __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __restrict__ gridU, const Geom& g, cplx* buf, const TW tw,
-                                               const size_t i0, const int tid, const XOrigin* xo_in = nullptr) {
+                                               const size_t i0, const int tid) {
     constexpr int HP = T / 2, NB = 3 * HP, S3 = L / 3;
     constexpr XLayout<L, NB, true> ix{};
     constexpr int NITEM = S3 * 3 * HP;                         // stored modes of one field group = items of the staging / split loops
@@ -697,7 +697,7 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     auto line_ok = [&](int p) { return i0 + 2 * p < plane; };
     auto st_buf = [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; };
     static_assert(T <= 8, "a tile lies inside one z block of Ty");
-    const XOrigin xo = xo_in ? *xo_in : x_origin(i0, g);
+    const XOrigin xo = x_origin(i0, g);
     auto spec_off = [&](int c, int kx, int p) -> size_t { return xo.base + c * xo.cs + kx * xo.ks + 2 * p; };
 
     // SMO_X_SEQ_PREFETCH = n: the first n (of SCNT) spectral items of B_f per thread are requested before the last forward stage of F1 instead
@@ -770,6 +770,8 @@ __device__ __forceinline__ void x_tile_adj_seq(const XSpec& sp, const double* __
     cplx old_sum[SMO_X_SEQ_LATE_SUM ? 1 : SCNT][2];
     // SMO_X_SEQ_REQ_EARLY=1: these requests (B_f's spectra in the first half, the running sum in the second) are issued before the whole forward
     // tail instead of before its last stage (G = 192: -1.3 %; at G = 384 the longer live ranges spill: +18 %)
+    // (parking part of omega's grid copy in the CU's idle LDS to make room for these at G = 384 was measured in round 4 and does not pay:
+    // profiles/r04_x384_levers.txt — the requested values compete with the radix-8 tail stages for the same registers, and those are worth more)
 #ifndef SMO_X_SEQ_REQ_EARLY
 #define SMO_X_SEQ_REQ_EARLY (only_2_and_3(L) && L <= 192)
 #endif
@@ -925,70 +927,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FU
     }
 }
 
-// The fused x passes as PERSISTENT workgroups with a DYNAMIC tile queue (round 4; SMO_KD_X_DYN=1).  gridDim.x = what fits the chip at once
-// (occupancy x 256 CUs); a workgroup loads the twiddle table once and then takes tiles from its XCD's queue — one atomicAdd per tile — until the
-// queue is empty.  Round 2's static form (tile = b, b + grid, ...) lost 27-37 % to imbalance; a queue has none.  queue[0..7] = next tile
-// group of XCD x (workgroup b sits on XCD b % 8, as the PAIRED mapping of kd_x_pass assumes), tiles dealt to the XCDs in groups of P = 8 / T
-// (the tiles of one 128-byte line of the spectra stay on one XCD); queue[8] counts finished workgroups: the last one zeroes the counters for the
-// next launch (same stream: ordered).
-template <int L, int MODE, int T, int NT, int PAIRED>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE == X_FUSED_ADJ_SEQ ? SMO_X_SEQ_WAVES : SMO_X_WAVES))) void kd_x_pass_dyn(XSpec sp, const double* __restrict__ gridU,
-                                                const cplx* __restrict__ tw_g, Geom g, unsigned* queue, unsigned ntiles, unsigned stagger) {
-    static_assert(MODE == X_FUSED_FWD || MODE == X_FUSED_ADJ_SEQ, "fused passes only");
-    static_assert(T <= 8, "tiles inside one z block");
-    constexpr int NB = 3 * (T / 2);
-    __shared__ cplx buf[XLayout<L, NB, true>::ELEMS];
-    constexpr bool HALF = (L > 192);
-    constexpr int NTW = HALF ? L / 2 : L;
-    __shared__ cplx tw_s[NTW];
-    __shared__ unsigned s_next;
-    for (int i = threadIdx.x; i < NTW; i += NT) tw_s[i] = tw_g[i];
-    constexpr unsigned P = PAIRED > 1 ? PAIRED : 1;
-    const unsigned xcd = blockIdx.x & 7u;
-    // all workgroups of a persistent grid start together and every tile takes the same time: without a spread they stay in phase (all loading,
-    // then all computing).  `stagger` > 0: workgroup b starts ((b * 2654435761) >> 26) % stagger sleep units (~2 us each at 2 GHz) late.
-    if (stagger) {
-        const unsigned d = ((blockIdx.x * 2654435761u) >> 20) % stagger;
-        for (unsigned i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-    // the ticket of the NEXT tile is drawn at the start of the current one: the atomic's round trip (a loaded-memory latency, several us when
-    // the chip streams) overlaps the tile's work instead of standing between two tiles with the whole workgroup waiting
-    unsigned ticket = 0;
-    if (threadIdx.x == 0) ticket = atomicAdd(&queue[xcd], 1u);
-    for (;;) {
-        __syncthreads();                                   // the previous tile's last reads of buf / s_next are done (first pass: the table is in place)
-        if (threadIdx.x == 0) s_next = ticket;
-        __syncthreads();
-        const unsigned q = s_next;
-        const size_t tile = (size_t)(q / P) * (8 * P) + xcd * P + q % P;
-        if (tile >= ntiles) break;                         // uniform: every thread reads the same s_next
-        if (threadIdx.x == 0) ticket = atomicAdd(&queue[xcd], 1u);
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));                      // per-tile copy of the thread index: keeps thread-derived addresses from being hoisted out of (and kept live across) the loop
-        // z-block-major Ty (the only layout this kernel is launched with): tile -> (z block, y, part of the 128-byte line); every division by a
-        // compile-time constant (G == L), the origin of the tile's spectra without one
-        constexpr unsigned PER = 8 / T;
-        const unsigned line = (unsigned)tile / PER, sub = (unsigned)tile - line * PER;
-        const unsigned zb = line / (unsigned)L, y = line - zb * (unsigned)L;
-        const size_t i0 = (size_t)y * g.Gzl + zb * 8u + sub * T;
-        const XOrigin xo{(size_t)zb * g.a * g.tyk + (size_t)y * 8 + sub * T, (size_t)(g.Gzl >> 3) * g.a * g.tyk, g.tyk};
-        if constexpr (MODE == X_FUSED_ADJ_SEQ) {
-            if constexpr (HALF) x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid, &xo);
-            else x_tile_adj_seq<L, T, NT>(sp, gridU, g, buf, (const cplx*)tw_s, i0, tid, &xo);
-        } else {
-            if constexpr (HALF) x_tile<L, MODE, T, NT>(sp, gridU, nullptr, g, buf, HalfTwiddles{tw_s, L / 2}, i0, tid, &xo);
-            else x_tile<L, MODE, T, NT>(sp, gridU, nullptr, g, buf, (const cplx*)tw_s, i0, tid, &xo);
-        }
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&queue[8], 1u) == gridDim.x - 1) {   // everybody else has drawn its last (empty) ticket already
-            for (int x = 0; x < 9; ++x) queue[x] = 0u;
-            __threadfence();
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // small per-mode kernels
 // ---------------------------------------------------------------------------------------------------------
@@ -1078,17 +1016,26 @@ public:
     size_t n_part_rows = 1;
     int k_zi = -1, k_zic = -1, k_yi = -1, k_yf = -1, k_xf = -1, k_xa = -1, k_zfu = -1, k_zfa = -1, k_misc = -1, k_ex = -1, k_dot = -1;
 
-    // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time
+    // snapshot n: every ck-th state is kept in the stack, the others live in (ck-1) scratch slots that hold ONE window at a time.
+    // Dense tail (round 4): from index dense_from (a multiple of ck) on EVERY state is kept — the HBM that a uniform interval leaves unused
+    // (256^3 x 1000 steps on one GPU: interval 2 = 200 GB of 288) buys that many windows less to recompute.  A state of the tail costs its
+    // adjoint step the z and y passes of the snapshot (no grid-side copy is kept for it), a recomputed window a whole forward step per ck
+    // adjoint steps plus the grid-side form of its last state: ~0.58 against ~1.07 ms per adjoint step at 256^3.
     int ck = 1, scratch_window = -1;
+    int dense_from = 1 << 30;
     cplx* d_scratch = nullptr;
     cplx* snap(int n) {
+        if (n >= dense_from) return d_stack + ((size_t)(dense_from / ck) + (size_t)(n - dense_from)) * 3 * nmode;
         const int r = n % ck;
         return r == 0 ? d_stack + (size_t)(n / ck) * 3 * nmode : d_scratch + (size_t)(r - 1) * 3 * nmode;
+    }
+    size_t stack_slots() const {
+        return dense_from > cfg.n_iters ? (size_t)cfg.n_iters / ck + 1 : (size_t)(dense_from / ck) + (size_t)(cfg.n_iters - dense_from) + 1;
     }
     size_t stack_elems(int k) const { return ((size_t)cfg.n_iters / k + 1 + (size_t)(k - 1)) * 3 * nmode; }
     // make state `idx` available (recompute its window from the preceding checkpoint if it is not resident)
     int ensure(int idx) {
-        if (idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
+        if (idx >= dense_from || idx % ck == 0 || scratch_window == idx / ck) return SMO_OK;
         const int w = idx / ck, last = std::min(cfg.n_iters, w * ck + ck - 1);
         scratch_window = w;
         // the forward steps that rebuild the window pass through the grid-side form Ty(B^_n) of the states they start from: keep it
@@ -1161,9 +1108,6 @@ public:
         { const char* e = getenv("SMO_KD_FUSE_NEXT"); fuse_next = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_KD_ADJ_SEQ"); adj_seq = !(e && atoi(e) == 0); }
         { const char* e = getenv("SMO_PEER_CHAINED"); chain_ok = !(e && atoi(e) == 0); }
-        { const char* e = getenv("SMO_KD_X_DYN"); if (e) x_dyn = atoi(e); }
-        { const char* e = getenv("SMO_KD_X_DYN_WG"); if (e) x_dyn_wg = atoi(e); }
-        { const char* e = getenv("SMO_KD_X_DYN_STAGGER"); if (e) x_dyn_stagger = atoi(e); }
         if (any_size) {
             fuse_next = false;                               // the run-time-length update kernel has no fused next pass
             plan = any_plan(3 * N / 2);
@@ -1212,7 +1156,12 @@ public:
         if (ck > cfg.n_iters) ck = cfg.n_iters;
         stack_bytes = stack_elems(ck) * sizeof(cplx);
         SMO_TRY(pool.upload(&d_tw, twiddles(g.G), stream));
-        SMO_TRY(pool.alloc(&d_stack, ((size_t)cfg.n_iters / ck + 1) * 3 * nmode));
+        // a context with checkpoint windows on ONE GPU allocates its stack last, sized with a dense tail from what is then free (below);
+        // with slabs the ranks would have to agree on the tail as they do on the interval: uniform there
+        // (an explicit interval — smo_config.ckpt > 1 — is kept as asked for unless SMO_KD_DENSE_FROM names a tail: the automatic tail belongs to ckpt = 0)
+        const bool tail_ok = ck > 1 && W == 1 && (cfg.ckpt == 0 || getenv("SMO_KD_DENSE_FROM")) &&
+                             !(getenv("SMO_SLAB_FORCE_EXCHANGE") && atoi(getenv("SMO_SLAB_FORCE_EXCHANGE")) == 1);
+        if (!tail_ok) SMO_TRY(pool.alloc(&d_stack, ((size_t)cfg.n_iters / ck + 1) * 3 * nmode));
         if (ck > 1) SMO_TRY(pool.alloc(&d_scratch, (size_t)(ck - 1) * 3 * nmode));
         {   // Ty stack: only when every snapshot is kept and 16 GB of HBM stay free afterwards (SMO_KD_TYSTACK=0 disables)
             const char* env = getenv("SMO_KD_TYSTACK");
@@ -1243,14 +1192,37 @@ public:
         if (W == 1 && !force_exchange) ys = zs;
         else SMO_TRY(pool.alloc(&ys, n_ex));
         SMO_TRY(pool.alloc(&d_red, 8));
-        SMO_TRY(pool.alloc(&d_queue, 16));
-        SMO_HIP(hipMemsetAsync(d_queue, 0, 16 * sizeof(unsigned), stream));
         SMO_TRY(pool.alloc(&d_G, 3 * nmode));
         SMO_TRY(pool.alloc(&d_nu, 3 * nmode));
         SMO_TRY(pool.alloc(&d_U, n_grid));
         n_part_rows = (cfg.cost == SMO_COST_INTEGRATED) ? (size_t)cfg.n_iters + 1 : 1;
         SMO_TRY(pool.alloc(&d_part, n_part_rows * NPART));
         h_part.resize(n_part_rows * NPART);
+        if (tail_ok) {
+            // dense tail: as many extra snapshots as the free HBM holds beyond the uniform stack (12 GB + the staging vectors of the host-buffer
+            // entry points stay free).  SMO_KD_DENSE_FROM = n forces the first dense index (rounded down to a multiple of the interval; tests),
+            // SMO_KD_DENSE_TAIL=0 keeps the uniform schedule.
+            const size_t snap_b = (size_t)3 * nmode * sizeof(cplx), base_slots = (size_t)cfg.n_iters / ck + 1;
+            size_t free_b = 0, total_b = 0;
+            SMO_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t keep = ((size_t)12 << 30) + 4 * n_grid * sizeof(double);
+            const size_t fit = free_b > keep ? (free_b - keep) / snap_b : 0;
+            long extra = (long)fit - (long)base_slots;
+            const char* off = getenv("SMO_KD_DENSE_TAIL");
+            if (off && atoi(off) == 0) extra = 0;
+            int df = 1 << 30;
+            if (const char* e = getenv("SMO_KD_DENSE_FROM")) df = std::max(0, atoi(e)) / ck * ck;
+            else if (extra > 0) {
+                // slots(D) = D / ck + (N - D) + 1 <= base_slots + extra, D a multiple of ck: the smallest such D
+                const long N = cfg.n_iters, need = N + 1 - (long)base_slots - extra;              // = D (1 - 1/ck) at least
+                long D = need <= 0 ? 0 : (need * ck + (ck - 2)) / (ck - 1);
+                D = (D + ck - 1) / ck * ck;
+                if (D <= N) df = (int)D;
+            }
+            if (df <= cfg.n_iters) dense_from = df;
+            SMO_TRY(pool.alloc(&d_stack, stack_slots() * 3 * nmode));
+            stack_bytes = (stack_slots() + (size_t)(ck - 1)) * snap_b;
+        }
         // algorithmic bytes per launch (every axis pass reads + writes its field; S0..S3 per component, per slab)
         const double S0 = 16.0 * nmode, S1 = 16.0 * g.al * g.m * (double)g.G, S2 = 16.0 * g.a * (double)g.G * g.Gzl, S3 = 8.0 * (double)g.G * g.G * g.Gzl;
         // second figure = compulsory HBM bytes of the kernel as fused (every input read once, every output written once): the
@@ -1453,20 +1425,8 @@ public:
             switch (mode) {
                 case X_TO_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_TO_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 case X_FROM_GRID: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FROM_GRID, S::XTG, S::XGNT>), tiles(S::XTG), dim3(S::XGNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
-                case X_FUSED_FWD:
-                    if ((x_dyn == 1 || x_dyn == 2) && q.tyl && plane % 8 == 0) {
-                        const unsigned nt = (unsigned)(plane / S::XT), wg = (unsigned)(x_dyn_wg > 0 ? x_dyn_wg : 4) * 256u;
-                        SMO_LAUNCH_T(t, (kd_x_pass_dyn<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), dim3(std::min(wg, nt)), dim3(S::XNT), 0, stream, sp, grid_in, d_tw, q, d_queue, nt, (unsigned)x_dyn_stagger);
-                        break;
-                    }
-                    SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
+                case X_FUSED_FWD: SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_FWD, S::XT, S::XNT, 8 / S::XT>), tiles(S::XT), dim3(S::XNT), 0, stream, sp, grid_in, grid_out, d_tw, q); break;
                 default:
-                    if constexpr (S::XTS == S::XT)
-                    if (adj_seq && (x_dyn == 1 || x_dyn == 3) && q.tyl && plane % 8 == 0) {
-                        const unsigned nt = (unsigned)(plane / S::XTS), wg = (unsigned)(x_dyn_wg > 0 ? x_dyn_wg : 3) * 256u;
-                        SMO_LAUNCH_T(t, (kd_x_pass_dyn<L, X_FUSED_ADJ_SEQ, S::XTS, S::XSNT, 8 / S::XTS>), dim3(std::min(wg, nt)), dim3(S::XSNT), 0, stream, sp, grid_in, d_tw, q, d_queue, nt, (unsigned)x_dyn_stagger);
-                        break;
-                    }
                     // adjoint: the field groups one after the other through the tile buffer (tiles as wide as the forward pass's), unless
                     // SMO_KD_ADJ_SEQ=0 asks for both at once in half-width tiles (round 1's kernel, kept for comparison)
                     if (adj_seq) SMO_LAUNCH_T(t, (kd_x_pass<L, X_FUSED_ADJ_SEQ, S::XTS, S::XSNT, 8 / S::XTS>), tiles(S::XTS), dim3(S::XSNT), 0, stream, sp, grid_in, grid_out, d_tw, q);
@@ -1628,9 +1588,6 @@ public:
     // chained: an exchange of the time loop (stage()), whose send buffer is next written by the pull of the exchange that follows it on the
     // same stream — the multi-device transport then skips its second rendezvous (comm.hpp).  SMO_PEER_CHAINED=0 keeps the full protocol.
     bool chain_ok = true;
-    // persistent fused x passes with a dynamic tile queue (kd_x_pass_dyn): SMO_KD_X_DYN = 1 both, 2 forward only, 3 adjoint only; SMO_KD_X_DYN_WG = workgroups per CU
-    int x_dyn = 0, x_dyn_wg = 0, x_dyn_stagger = 0;
-    unsigned* d_queue = nullptr;
     int exchange(bool to_y, int nf, int k, hipStream_t s, bool chained = false) {
         if (!exchanging()) return SMO_OK;
         const size_t off = (size_t)k * (size_t)cfg.world * 2 * tzc;
@@ -1867,7 +1824,7 @@ public:
             SMO_TRY(fwd_enqueue(X[0], X[1]));
         }
         issue_ms_fwd = (now_ms() - t_in) - (comm.wait_ms() - w_in);
-        scratch_window = (ck > 1) ? (N - 1) / ck : -1;       // the scratch slots now hold the last window
+        scratch_window = (ck > 1 && dense_from > 0) ? (std::min(N, dense_from) - 1) / ck : -1;       // the scratch slots now hold the last window that was not kept whole
         const size_t rows = integ ? (size_t)N + 1 : 1;
         SMO_HIP(hipMemcpyAsync(h_part.data(), d_part, rows * NPART * sizeof(double), hipMemcpyDeviceToHost, stream));
         SMO_HIP(hipStreamSynchronize(stream));
@@ -1939,6 +1896,7 @@ public:
         if (key == 2) return (double)graph_replays;
         if (key == 3) return (double)g.tyl;
         if (key == 4) return issue_ms_fwd + issue_ms_adj;
+        if (key == 5) return dense_from > cfg.n_iters ? -1.0 : (double)dense_from;
         return d_tystack ? (double)((size_t)cfg.n_iters * fld * sizeof(cplx)) : 0.0;
     }
 

@@ -330,6 +330,38 @@ def test_windowed_checkpointing_is_bit_identical(ckpt, n, cost, adj):
     ref.drop_contexts(); dom.drop_contexts()
 
 
+@pytest.mark.parametrize("ckpt,n,dense", [(2, 9, 4), (3, 11, 6), (4, 8, 0), (2, 7, 6)])
+@pytest.mark.parametrize("cost,adj", [("Final", "Discrete"), ("Integrated", "Continuous")])
+def test_checkpoint_schedule_with_a_dense_tail_is_bit_identical(ckpt, n, dense, cost, adj, monkeypatch):
+    """The non-uniform schedule of round 4: windows of `ckpt` states up to index `dense`, EVERY state kept from there on (what the HBM left
+    over by a uniform interval buys at 256^3 on one GPU).  Same kernels on the same states: J and both gradients equal the keep-all run bit
+    for bit, snapshot reads on both sides of the boundary too."""
+    N = 16
+    ref = kdyn.KDynDomain(N)
+    B, U = _fields(ref.G, dirty=True)
+    bufr = kdyn.GEN_BUFFER(N, ref, n)
+    args = [1.0, 1e-2, n, n]
+    J0 = kdyn.FWD_Solve_IVP_Lin([B, U], ref, *args, bufr, cost, adj)
+    g0 = kdyn.ADJ_Solve_IVP_Lin([B, U], ref, *args, bufr, cost, adj)
+    monkeypatch.setenv("SMO_KD_DENSE_FROM", str(dense))
+    dom = kdyn.KDynDomain(N, ckpt=ckpt)
+    buf = kdyn.GEN_BUFFER(N, dom, n)
+    J1 = kdyn.FWD_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)
+    ctx = dom.context(*args[:3], cost)
+    assert ctx.get(0) == ckpt and ctx.get(5) == dense // ckpt * ckpt
+    g1 = kdyn.ADJ_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)
+    assert J1 == J0 and np.array_equal(g1[0], g0[0]) and np.array_equal(g1[1], g0[1])
+    g2 = kdyn.ADJ_Solve_IVP_Lin([B, U], dom, *args, buf, cost, adj)
+    assert np.array_equal(g2[0], g0[0]) and np.array_equal(g2[1], g0[1])
+    for i in range(n + 1):
+        assert np.array_equal(buf['A_fwd'][:, :, :, i], bufr['A_fwd'][:, :, :, i]), i
+    monkeypatch.delenv("SMO_KD_DENSE_FROM")
+    uni = kdyn.KDynDomain(N, ckpt=ckpt)                     # an explicit interval without the knob stays uniform
+    kdyn.FWD_Solve_IVP_Lin([B, U], uni, *args, kdyn.GEN_BUFFER(N, uni, n), cost, adj)
+    assert uni.context(*args[:3], cost).get(5) == -1
+    ref.drop_contexts(); dom.drop_contexts(); uni.drop_contexts()
+
+
 def test_reference_ic_recipe_with_device_prep():
     """Generate_IC(reference_recipe=True): curl-type field of filtered seed-42 noise, smoothed by 101 device steps (KDYN:183-317)."""
     N = 16
