@@ -302,6 +302,7 @@ def cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, workers, sample_steps=4, cpus=No
             old = None
     try:
         o = ThreadedKDynOracle(N, Rm=Rm, dt=dt, N_ITERS=sample_steps, threads=workers)
+        o.prewarm()                                   # work arrays allocated and touched before the clock starts
         t0 = time.perf_counter()
         o.forward([B, U]); o.adjoint([B, U])
         el = time.perf_counter() - t0

@@ -195,6 +195,39 @@ class ThreadedKDynOracle(KDynOracle):
         super().__init__(*args, **kw)
         self.nt = int(threads)
         self.pool = ThreadPoolExecutor(self.nt) if self.nt > 1 else None
+        # Work arrays are REUSED (named scratch arrays, small rings for the results): a fresh 0.4-1.4 GB array per stage is first touched page by
+        # page under the process-wide mmap lock, which neither one thread nor sixteen get through quickly (the 16-thread leg ran 4x the 1-thread
+        # one before this).  Ring sizes: no stage keeps more than 4 grid fields / 7 coefficient fields of earlier stages alive.
+        self._named, self._rings, self._ring_pos = {}, {}, {}
+
+    def prewarm(self):
+        """Allocate and touch every reusable work array (outside a timed region: first-touch page faults are not the algorithm)."""
+        G, a, m = self.G, self.a, self.m
+        for name, shape, dt in (("t", (a, m, G), complex), ("p", (a, m, G), complex), ("q", (a, G, G), complex), ("r", (G // 2 + 1, G, G), complex),
+                                ("Ug", (3, G, G, G), float)):
+            self._par(lambda s, b=self._tmp(name, shape, dt): b[s].fill(0), shape[0])
+        for kind, n in (("grid", 5), ("coef", 10)):
+            for _ in range(n):
+                b = self._ring(kind)
+                self._par(lambda s, b=b: b[:, s].fill(0), b.shape[1])
+        self.stack = np.empty((self.N_ITERS + 1, 3, a, m, m), dtype=complex)
+        self._par(lambda s: self.stack[s].fill(0), self.N_ITERS + 1)
+
+    def _tmp(self, name, shape, dtype):
+        b = self._named.get(name)
+        if b is None or b.shape != tuple(shape) or b.dtype != np.dtype(dtype):
+            b = self._named[name] = np.empty(shape, dtype=dtype)
+        return b
+
+    def _ring(self, kind):
+        G = self.G
+        shape, dtype, n = (((3, G, G, G), float, 5) if kind == "grid" else ((3, self.a, self.m, self.m), complex, 10))
+        r = self._rings.setdefault(kind, [None] * n)
+        i = self._ring_pos.get(kind, 0)
+        self._ring_pos[kind] = (i + 1) % n
+        if r[i] is None:
+            r[i] = np.empty(shape, dtype=dtype)
+        return r[i]
 
     def _par(self, f, n):
         """f(slice) over [0, n) in contiguous chunks, one per thread (a few per thread for balance)."""
@@ -210,10 +243,10 @@ class ThreadedKDynOracle(KDynOracle):
     def to_coeff(self, g, out=None):
         w, G = self.workers, self.G
         c = sfft.rfft(g, axis=0, workers=w)[:self.a]
-        c = sfft.fft(c, axis=1, workers=w)
-        t = np.empty((self.a, self.m, G), dtype=complex)
+        c = sfft.fft(c, axis=1, workers=w, overwrite_x=True)
+        t = self._tmp("t", (self.a, self.m, G), complex)
         self._par(lambda s: t.__setitem__(s, c[s][:, self.sel]), self.a)
-        t = sfft.fft(t, axis=2, workers=w)
+        t = sfft.fft(t, axis=2, workers=w, overwrite_x=True)
         if out is None:
             out = np.empty((self.a, self.m, self.m), dtype=complex)
         sc = float(G) ** 3
@@ -222,21 +255,21 @@ class ThreadedKDynOracle(KDynOracle):
 
     def to_grid(self, c, out=None):
         G, w = self.G, self.workers
-        p = np.empty((self.a, self.m, G), dtype=complex)
+        p = self._tmp("p", (self.a, self.m, G), complex)
 
         def pad_z(s):
             p[s] = 0.
             p[s][:, :, self.sel] = c[s]
         self._par(pad_z, self.a)
-        p = sfft.ifft(p, axis=2, workers=w)
-        q = np.empty((self.a, G, G), dtype=complex)
+        p = sfft.ifft(p, axis=2, workers=w, overwrite_x=True)
+        q = self._tmp("q", (self.a, G, G), complex)
 
         def pad_y(s):
             q[s] = 0.
             q[s][:, self.sel] = p[s]
         self._par(pad_y, self.a)
-        q = sfft.ifft(q, axis=1, workers=w)
-        r = np.empty((G // 2 + 1, G, G), dtype=complex)
+        q = sfft.ifft(q, axis=1, workers=w, overwrite_x=True)
+        r = self._tmp("r", (G // 2 + 1, G, G), complex)
 
         def pad_x(s):
             r[s] = 0.
@@ -254,30 +287,30 @@ class ThreadedKDynOracle(KDynOracle):
     def vec_to_coeff(self, X):
         G = self.G
         X = np.asarray(X, dtype=float).reshape(3, G, G, G)
-        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        out = self._ring("coef")
         for i in range(3):
             self.to_coeff(X[i], out=out[i])
         return out
 
     def coeff_to_vec(self, C):
-        return self.grid3(C).reshape(-1)
+        return self.grid3(C).reshape(-1).copy()          # the caller keeps it: not a view of a ring slot
 
-    def grid3(self, C):
-        G = self.G
-        out = np.empty((3, G, G, G))
+    def grid3(self, C, out=None):
+        if out is None:
+            out = self._ring("grid")
         for i in range(3):
             self.to_grid(C[i], out=out[i])
         return out
 
     def coeff3(self, F):
-        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        out = self._ring("coef")
         for i in range(3):
             self.to_coeff(F[i], out=out[i])
         return out
 
     # -- per-mode algebra, chunked over kx --------------------------------------------------------------------------------------
     def _over_kx(self, f):
-        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        out = self._ring("coef")
         self._par(lambda s: out.__setitem__((slice(None), s), f(s)), self.a)
         return out
 
@@ -285,7 +318,7 @@ class ThreadedKDynOracle(KDynOracle):
         return self._over_kx(lambda s: V[:, s] - self.K[:, s] * ((self.K[:, s] * V[:, s]).sum(0) / self.k2s[s]))
 
     def curl(self, V):
-        out = np.empty((3, self.a, self.m, self.m), dtype=complex)
+        out = self._ring("coef")
 
         def f(s):
             K, v = self.K[:, s], V[:, s]
@@ -296,7 +329,7 @@ class ThreadedKDynOracle(KDynOracle):
         return out
 
     def cross(self, A, B):
-        out = np.empty_like(A)
+        out = self._ring("grid") if A.shape == (3, self.G, self.G, self.G) else np.empty_like(A)
 
         def f(s):
             a, b = A[:, s], B[:, s]
@@ -324,8 +357,9 @@ class ThreadedKDynOracle(KDynOracle):
     def forward(self, X):
         n_it, dt = self.N_ITERS, self.dt
         Bh = self.vec_to_coeff(X[0])
-        self.Ug = self.grid3(self.vec_to_coeff(X[1]))
-        self.stack = np.zeros((n_it + 1, 3, self.a, self.m, self.m), dtype=complex)      # step index FIRST here: contiguous snapshots
+        self.Ug = self.grid3(self.vec_to_coeff(X[1]), out=self._tmp("Ug", (3, self.G, self.G, self.G), float))
+        if self.stack is None or self.stack.shape[0] != n_it + 1:
+            self.stack = np.zeros((n_it + 1, 3, self.a, self.m, self.m), dtype=complex)      # step index FIRST here: contiguous snapshots
         J = 0.
         for n in range(n_it + 1):
             self.stack[n] = Bh
