@@ -312,111 +312,6 @@ static inline void launch_x(hipStream_t stream, const XDesc* xd, int n, int dir,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Column tile through the whole grid stage of a time step (round 4): x lines of NIN coefficient fields -> grid,
-// the pointwise products at every grid point of the tile, NOUT product fields -> x coefficients, in ONE kernel instead of pois_x_to_grid +
-// pois_nl / pois_adj_products + pois_x_to_coeff (three launches and two round trips of 8-11 grid fields through L2 per half step; the path
-// is bound by the hand-over between short dependent kernels).  A workgroup owns ZT = 2 NBF z columns (NBF packed transforms per field) for all
-// x; the NIN * NBF transforms sit interleaved in the LDS (PosMajor), the products replace the first NOUT fields in place — a thread reads and
-// writes its own grid points only —, and the forward transforms run over those.  MODE 0: forward step (POIS:911-921, pois_nl; + the energy
-// partial of the step); MODE 1: adjoint step (NLtermAdj, POIS:1510-1524, pois_adj_products).  Same arithmetic per element as the three
-// kernels it replaces (they stay as the SMO_POIS_XFUSE=0 path and for the lengths / shapes this one does not take).
-// ---------------------------------------------------------------------------------------------------------
-template <int L, int NIN, int NOUT, int NBF, int MODE, int FNT>
-__global__ __launch_bounds__(FNT) void pois_x_fused(const XDesc* __restrict__ din, const XDesc* __restrict__ dout, const cplx* __restrict__ tw_g, int Nz, int a,
-                                                     int ada, double k1, const double* __restrict__ Wz, double* __restrict__ part, double fscale, int forcing) {
-    constexpr int NB = NIN * NBF, NBO = NOUT * NBF, ZT = 2 * NBF;
-    static_assert(NOUT <= NIN, "the products replace the first NOUT input fields in place");
-    constexpr PosMajor<NB> ix{};
-    __shared__ cplx buf[NB * L];
-    __shared__ cplx tw[L];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < L; i += FNT) tw[i] = tw_g[i];
-    __syncthreads();
-    const int z0 = blockIdx.x * ZT;
-    // ---- coefficients -> grid: transform b = f * NBF + t packs the columns z0 + 2t (real part) and z0 + 2t + 1 (imaginary part) of field f ----
-    auto mode = [&](const XDesc& d, int n, int z) -> cplx {
-        if (z >= Nz) return mk(0, 0);
-        const double re = d.src[(size_t)(2 * n) * Nz + z], im = n == 0 ? 0.0 : d.src[(size_t)(2 * n + 1) * Nz + z];
-        switch (d.kind) {
-            case XK_ID: { const double k = k1 * n; return mk(-k * im, k * re); }
-            case XK_IN: return mk(re / L, im / L);
-            case XK_IN_DA: return n < ada ? mk(re / L, im / L) : mk(0, 0);
-            default: return mk(re, im);
-        }
-    };
-    auto ld0 = [&](int b, int pos) -> cplx {
-        if (pos >= a && pos <= L - a) return mk(0, 0);
-        const int f = b / NBF, t = b - f * NBF, n = pos < a ? pos : L - pos;
-        const XDesc d = din[f];
-        const cplx A = mode(d, n, z0 + 2 * t), B = mode(d, n, z0 + 2 * t + 1);
-        return pos < a ? mk(A.re - B.im, A.im + B.re) : mk(A.re + B.im, B.re - A.im);
-    };
-    fft_inplace_ix<L, true, NB, FNT, true, false, true>(buf, ix, tw, tid, ld0, [&](int b, int x, cplx v) { buf[ix(b, x)] = v; });
-    __syncthreads();
-    // ---- products at the tile's grid points (.re / .im = the two columns of a pair) ----
-    double acc = 0.0;
-    for (int i = tid; i < L * NBF; i += FNT) {
-        const int x = i / NBF, t = i - x * NBF, z = z0 + 2 * t;
-        cplx g[NIN], o[NOUT];
-#pragma unroll
-        for (int f = 0; f < NIN; ++f) g[f] = buf[ix(f * NBF + t, x)];
-        if constexpr (MODE == 0) {                          // g = [u, ux, uz, v, vx, vz, rx, rz] -> [NLu, NLv, NLr]
-            static_assert(NIN == 8 && NOUT == 3, "forward step: 8 grids in, 3 products out");
-            o[0] = mk(-g[0].re * g[1].re - g[3].re * g[2].re, -g[0].im * g[1].im - g[3].im * g[2].im);
-            o[1] = mk(-g[0].re * g[4].re - g[3].re * g[5].re, -g[0].im * g[4].im - g[3].im * g[5].im);
-            o[2] = mk(-g[0].re * g[6].re - g[3].re * g[7].re, -g[0].im * g[6].im - g[3].im * g[7].im);
-            if (z < Nz) acc += Wz[z] * (g[0].re * g[0].re + g[3].re * g[3].re);
-            if (z + 1 < Nz) acc += Wz[z + 1] * (g[0].im * g[0].im + g[3].im * g[3].im);
-        } else {                                            // g = [v1, v2, v3, u, v, ux, vx, rx, uz, vz, rz] -> [adju, adjux, adjuz, adjv, adjvx, adjvz, adjrx, adjrz, (fu, fv)]
-            static_assert(NIN == 11 && (NOUT == 8 || NOUT == 10), "adjoint step: 11 grids in, 8 (+2 forcing) products out");
-            o[0] = mk(-g[5].re * g[0].re - g[6].re * g[1].re - g[7].re * g[2].re, -g[5].im * g[0].im - g[6].im * g[1].im - g[7].im * g[2].im);
-            o[1] = mk(-g[3].re * g[0].re, -g[3].im * g[0].im);
-            o[2] = mk(-g[4].re * g[0].re, -g[4].im * g[0].im);
-            o[3] = mk(-g[8].re * g[0].re - g[9].re * g[1].re - g[10].re * g[2].re, -g[8].im * g[0].im - g[9].im * g[1].im - g[10].im * g[2].im);
-            o[4] = mk(-g[3].re * g[1].re, -g[3].im * g[1].im);
-            o[5] = mk(-g[4].re * g[1].re, -g[4].im * g[1].im);
-            o[6] = mk(-g[3].re * g[2].re, -g[3].im * g[2].im);
-            o[7] = mk(-g[4].re * g[2].re, -g[4].im * g[2].im);
-            if constexpr (NOUT == 10) {
-                const double w0 = z < Nz ? fscale * Wz[z] : 0.0, w1 = z + 1 < Nz ? fscale * Wz[z + 1] : 0.0;
-                o[8] = mk(w0 * g[3].re, w1 * g[3].im);
-                o[9] = mk(w0 * g[4].re, w1 * g[4].im);
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < NOUT; ++f) buf[ix(f * NBF + t, x)] = o[f];
-    }
-    __syncthreads();
-    // ---- grid -> coefficients of the NOUT product fields (the first NBO transforms of the tile) ----
-    fft_inplace_ix<L, false, NBO, FNT, true, true, true>(buf, ix, tw, tid, [&](int b, int x) { return buf[ix(b, x)]; },
-                                                         [&](int b, int pos, cplx v) { buf[ix(b, pos)] = v; });
-    __syncthreads();
-    for (int t = tid; t < NOUT * ZT * a; t += FNT) {       // Hermitian split: column z0 + q of mode n of product field f (q fastest: 16-byte runs per row)
-        const int q = t % ZT, r = t / ZT, f = r % NOUT, n = r / NOUT, b = f * NBF + (q >> 1), z = z0 + q;
-        if (z >= Nz) continue;
-        const XDesc d = dout[f];
-        const cplx hl = buf[ix(b, n)], hh = n == 0 ? hl : buf[ix(b, L - n)];
-        const cplx F = (q & 1) ? mk(0.5 * (hl.im + hh.im), -0.5 * (hl.re - hh.re)) : mk(0.5 * (hl.re + hh.re), 0.5 * (hl.im - hh.im));
-        cplx c;
-        switch (d.kind) {
-            case XK_F: c = mk(F.re / L, F.im / L); break;
-            case XK_F_DA: c = n < ada ? mk(F.re / L, F.im / L) : mk(0, 0); break;
-            case XK_FNDA: { const double k = k1 * n; c = mk(k * F.im, -k * F.re); break; }
-            default: c = F;
-        }
-        d.dst[(size_t)(2 * n) * Nz + z] = c.re;
-        d.dst[(size_t)(2 * n + 1) * Nz + z] = n == 0 ? 0.0 : c.im;
-    }
-    if (MODE == 0) {                                        // the step's energy partial of this tile (rows of NPART partials, summed on the host)
-        __shared__ double red[FNT / 64];
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if ((tid & 63) == 0) red[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) { double s = 0.0; for (int w = 0; w < FNT / 64; ++w) s += red[w]; part[blockIdx.x] = s; }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // per-wavenumber operator apply: [out fields ; out extras]_n = S_n [in fields ; in extras]_n   (complex)
 //   S_n dense (nout*Nz + xout) x (nin*Nz + xin); fields are [f][2a][Nz] coefficient arrays, extras [2a][3] (row 2n = Re, 2n+1 = Im).
 // One wave per output row; the operators are streamed once: this is the HBM-bound part of a time step.
@@ -1051,13 +946,10 @@ public:
             const char* e = getenv("SMO_POIS_XFFT");
             use_xfft = !(e && atoi(e) == 0) && Nz % 2 == 0 && with_xfft_length(Nx, [](auto) {});
             if (use_xfft) SMO_TRY(pool.upload(&d_twx, twiddles(Nx), stream));
-            const char* f = getenv("SMO_POIS_XFUSE");
-            // (the whole grid stage as one column-tile kernel, pois_x_fused: correct, but 96 workgroups of serial work lose to the 264 + 24 + 240 of the
-            // kernels it replaces — 30.7 us against 11.8 + 6.9 + 11.8 at 384 x 192, profiles/r04_poiseuille_fusion.txt; SMO_POIS_XFUSE=1 selects it)
-            use_xfuse = use_xfft && f && atoi(f) == 1;
+            // SMO_POIS_XPROD=1: the pointwise products folded into the loads of the forward x transform (12 instead of 14 launches per step pair;
+            // measured: no gain, profiles/r04_poiseuille_fusion.txt, where the one-kernel grid stage that was tried as well is recorded)
             const char* pr = getenv("SMO_POIS_XPROD");
-            use_xprod = use_xfft && !use_xfuse && !(pr && atoi(pr) == 0);
-            if (const char* c = getenv("SMO_POIS_XFUSE_CFG")) sscanf(c, "%d,%d", &xfuse_nbf, &xfuse_nt);
+            use_xprod = use_xfft && pr && atoi(pr) == 1;
         }
         // ---- base state rho = -erf(z/delta)/2 (n = 0 only), de-aliased (POIS:932-936) ------------------------------------------------
         {
@@ -1194,7 +1086,6 @@ public:
         k_apply_adj = timing.add_class(use_hodlr ? "pois_apply_hodlr (transposed tau operator)" : "pois_apply (transposed tau operator)", op_bytes_adj, op_bytes_adj);
         k_point = timing.add_class("pois pointwise", 0.0);
         k_xfft = timing.add_class("pois_x (x transforms, LDS FFT)", 0.0);
-        k_xfuse = timing.add_class("pois_x_fused (x lines -> grid, products, -> x coefficients: one column tile)", 0.0);
         return SMO_OK;
     }
 
@@ -1205,11 +1096,6 @@ public:
         return SMO_OK;
     }
     int state_grids(bool initial) { SMO_TRY(run(initial ? Fz : Fz1)); return run(Fx); }
-    // the grid stage of a step as ONE column-tile kernel (pois_x_fused): x lines -> grid, products, -> x coefficients.  SMO_POIS_XFUSE=0 keeps the
-    // three kernels.  Lengths up to 384 take 4 z columns per workgroup (the adjoint tile: 11 fields x 2 packed transforms x Nx x 16 B = 135 KB
-    // at Nx = 384), 768 takes 2.
-    bool use_xfuse = false;
-    int k_xfuse = -1;
     // the products folded into the loads of the grid -> coefficient transform (pois_x_prod_to_coeff): default; SMO_POIS_XPROD=0 keeps pois_nl /
     // pois_adj_products + pois_x_to_coeff
     bool use_xprod = false;
@@ -1223,36 +1109,6 @@ public:
         if (!ok) { set_error("POIS: no x FFT for Nx = %d", Nx); return SMO_ERR_STATE; }
         return SMO_OK;
     }
-    int xfuse_nbf = 0, xfuse_nt = 0;                 // SMO_POIS_XFUSE_CFG="nbf,nt" (experiment: tile width and threads of the fused kernel at Nx = 384)
-    template <int MODE> int fused_grid_stage(const Phase& in, const Phase& out, int nout, double* part, double fscale, int forcing) {
-        ScopedTimer t(timing, k_xfuse, stream);
-        bool ok = with_xfft_length(Nx, [&](auto l) {
-            constexpr int LL = decltype(l)::value;
-            auto go = [&](auto nbf, auto nt) {
-                constexpr int NBF = decltype(nbf)::value, FNT = decltype(nt)::value;
-                const dim3 grid((unsigned)((Nz + 2 * NBF - 1) / (2 * NBF)));
-                if constexpr (MODE == 0)
-                    hipLaunchKernelGGL((pois_x_fused<LL, 8, 3, NBF, 0, FNT>), grid, dim3(FNT), 0, stream, in.xd, out.xd, d_twx, Nz, a, ada, k1, d_Wz, part, fscale, forcing);
-                else if (nout == 10)
-                    hipLaunchKernelGGL((pois_x_fused<LL, 11, 10, NBF, 1, FNT>), grid, dim3(FNT), 0, stream, in.xd, out.xd, d_twx, Nz, a, ada, k1, d_Wz, part, fscale, forcing);
-                else
-                    hipLaunchKernelGGL((pois_x_fused<LL, 11, 8, NBF, 1, FNT>), grid, dim3(FNT), 0, stream, in.xd, out.xd, d_twx, Nz, a, ada, k1, d_Wz, part, fscale, forcing);
-            };
-            using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-            if constexpr (LL == 384) {
-                if (xfuse_nbf == 1 && xfuse_nt == 256) return go(I1(), std::integral_constant<int, 256>());
-                if (xfuse_nbf == 1 && xfuse_nt == 512) return go(I1(), std::integral_constant<int, 512>());
-                if (xfuse_nbf == 1 && xfuse_nt == 1024) return go(I1(), std::integral_constant<int, 1024>());
-                if (xfuse_nbf == 2 && xfuse_nt == 512) return go(I2(), std::integral_constant<int, 512>());
-                if (xfuse_nbf == 2 && xfuse_nt == 1024) return go(I2(), std::integral_constant<int, 1024>());
-            }
-            if constexpr (LL <= 384) go(I2(), std::integral_constant<int, 256>());
-            else go(I1(), std::integral_constant<int, 256>());
-        });
-        if (!ok) { set_error("POIS: no fused grid stage for Nx = %d", Nx); return SMO_ERR_STATE; }
-        return SMO_OK;
-    }
-
     int nl_and_energy(int step) {
         ScopedTimer t(timing, k_point, stream);
         hipLaunchKernelGGL(pois_nl, dim3(NPART), dim3(256), 0, stream, GR, PR, d_Wz, d_part + (size_t)step * NPART, nG, Nz);
@@ -1263,10 +1119,7 @@ public:
     int fwd_loop() {
         const int N = cfg.n_iters;
         for (int n = 0; n < N; ++n) {
-            if (use_xfuse) {
-                SMO_TRY(run(n == 0 ? Fz : Fz1));
-                SMO_TRY(fused_grid_stage<0>(Fx, Fxf, 3, d_part + (size_t)n * NPART, 0.0, 0));
-            } else if (use_xprod) {
+            if (use_xprod) {
                 SMO_TRY(state_grids(n == 0));
                 SMO_TRY(prod_to_coeff<0>(Fxf, 3, d_part + (size_t)n * NPART, 0.0));
             } else {
@@ -1292,9 +1145,7 @@ public:
             SMO_TRY(solve_adj());
             SMO_TRY(run(Az, -1, ((long long)(intptr_t)snap(idx) - (long long)(intptr_t)cur3) / (long long)sizeof(double)));      // the forward state's lines straight from snapshot idx
             const int np = forcing ? 10 : 8;
-            if (use_xfuse) {
-                SMO_TRY(fused_grid_stage<1>(Ax, Axf, np, nullptr, -cfg.dt / V, forcing ? 1 : 0));
-            } else if (use_xprod) {
+            if (use_xprod) {
                 SMO_TRY(run(Ax));
                 SMO_TRY(prod_to_coeff<1>(Axf, np, nullptr, -cfg.dt / V));
             } else {
@@ -1320,7 +1171,7 @@ public:
         SMO_HIP(hipMemcpyAsync(GR, X[0], 2 * nG * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemsetAsync(S6, 0, 6 * nC * sizeof(double), stream));
         SMO_HIP(hipMemsetAsync(d_X3, 0, (size_t)2 * a * 3 * sizeof(double), stream));      // rows of the modes n >= ada stay zero
-        if (use_xfuse || use_xprod) SMO_HIP(hipMemsetAsync(d_part, 0, (size_t)N * NPART * sizeof(double), stream));      // the column tiles write Nz / 8 (Nz / 4) of a row's NPART partials
+        if (use_xprod) SMO_HIP(hipMemsetAsync(d_part, 0, (size_t)N * NPART * sizeof(double), stream));      // its column tiles write Nz / 8 of a row's NPART partials
         SMO_TRY(run(F0x)); SMO_TRY(run(F0z)); SMO_TRY(run(F0d));
         SMO_HIP(hipMemcpyAsync(S6 + 2 * nC, d_rho0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));
         SMO_HIP(hipMemcpyAsync(S6 + 5 * nC, d_rz0, nC * sizeof(double), hipMemcpyDeviceToDevice, stream));

@@ -256,15 +256,13 @@ def test_x_transforms_as_ffts_match_the_dense_products(Nx, Nz, n, s, monkeypatch
 
 
 @pytest.mark.parametrize("Nx,Nz,n,s", [(24, 24, 6, 0), (48, 66, 7, 1), (96, 48, 6, 0), (192, 96, 4, 1), (384, 192, 3, 0), (768, 48, 2, 1)])
-def test_fused_grid_stage_matches_the_three_kernels(Nx, Nz, n, s, monkeypatch):
-    """Round 4: the grid stage of a step with the pointwise kernel folded into the loads of the forward x transform (pois_x_prod_to_coeff, the
-    default) and as ONE column-tile kernel (pois_x_fused, SMO_POIS_XFUSE=1) against the three kernels they replace: both cost functionals (s = 0 carries the two forcing products: 10 instead of
-    8 product fields in the adjoint tile), a ragged last tile of z columns (Nz = 66), the largest adjoint tile (Nx = 384: 135 KB of LDS) and
-    the 2-column tiles of Nx = 768.  Same arithmetic per element: 1e-12."""
+def test_products_folded_into_the_x_transform_match_the_separate_kernels(Nx, Nz, n, s, monkeypatch):
+    """Round 4: the grid stage of a step with the pointwise kernel folded into the loads of the forward x transform (pois_x_prod_to_coeff,
+    SMO_POIS_XPROD=1) against the separate kernels (the default): both cost functionals (s = 0 carries the two forcing products: 10 instead
+    of 8 product fields), a ragged last tile of z columns (Nz = 66).  Same arithmetic per element: 1e-12."""
     _, U0 = pz.Generate_IC(Nx, Nz, E_0=0.02, seed=11)
     res = {}
-    for mode in ("0", "1", "prod"):
-        monkeypatch.setenv("SMO_POIS_XFUSE", "1" if mode == "1" else "0")
+    for mode in ("0", "prod"):
         monkeypatch.setenv("SMO_POIS_XPROD", "1" if mode == "prod" else "0")
         dom = pz.PoiseuilleDomain(Nx, Nz)
         buf = pz.GEN_BUFFER(Nx, Nz, dom, n)
@@ -276,7 +274,7 @@ def test_fused_grid_stage_matches_the_three_kernels(Nx, Nz, n, s, monkeypatch):
         assert J2 == J
         dom.drop_contexts()
     J3, g3, u3, b3 = res["0"]
-    for mode in ("1", "prod"):        # "1": the whole grid stage in one column-tile kernel; "prod" (the default): the products folded into the loads of the forward x transform
+    for mode in ("prod",):
         Jf, gf, uf, bf = res[mode]
         assert abs(Jf - J3) <= 1e-12 * abs(J3), (mode, Jf, J3)
         assert rel(gf, g3) < 1e-12 and rel(uf, u3) < 1e-12 and rel(bf, b3) < 1e-12, (mode, rel(gf, g3), rel(uf, u3), rel(bf, b3))
