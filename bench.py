@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=None, help="override N_ITERS (the result is then flagged as reduced)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=None, help="time steps of the CPU baseline sample (default 4)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short SH23 / SHB23 lines appended to the default run")
     ap.add_argument("--no-host-vectors", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg of the kdyn workload")
     ap.add_argument("--replicas", action="store_true", help="N>1: run N independent gradients instead of the slab decomposition")
@@ -653,7 +654,7 @@ def bench_kdyn(a, torch, rank, world):
         roof["inner_product"] = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        ss = getattr(a, "cpu_sample_steps", None) or 4
+        ss = getattr(a, "cpu_sample_steps", None) or 4      # (--cpu-sample-steps; the 256^3 leg of the default run takes 2)
         topo = cpu_topology()
         cpu = cpu_baseline_kdyn(N, Rm, dt, n_iters, B, U, 1, sample_steps=ss, cpus=topo["cpus_used"][:1])
         # the all-core leg: ONE socket's physical cores (what north_star's "single-socket CPU baseline" names), never the whole box's threads
