@@ -18,8 +18,25 @@ P = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name.replace("void smo::(anonymous namespace)::", ""))
-    return name.strip()
+    name = name.replace("void ", "").replace("smo::(anonymous namespace)::", "").replace("smo::", "")
+    return re.sub(r"\(.*", "", name).strip()
+
+
+def sq_row(path):
+    """tools/profile_sq.sh summary: the dominant kernel's wave-cycle split and LDS conflict share."""
+    txt = open(path).read()
+    out = []
+    for kern in re.findall(r"^(kd_x_pass<\d+, 4, [^>]*>|kd_z_forward<\d+, 1, 1, [^>]*>)\s*$", txt, flags=re.M):
+        blk = txt[txt.index(kern):].split("\nkd_", 1)[0]
+        c = {m.group(1): float(m.group(2)) for m in re.finditer(r"(SQ_\w+)\s+avg ([0-9.e+]+)", blk)}
+        if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
+            s = "`%s`: parked %.0f %%, issue-stalled %.0f %%, issuing %.0f %% of the wave cycles" % (
+                kern, 100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
+                100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"])
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                s += ", LDS bank conflicts %.1f %% of the LDS-active cycles" % (100 * c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"])
+            out.append(s)
+    return "SQ counters per kernel (`tools/profile_sq.sh`, six `--pmc` passes): " + "; ".join(out)
 
 
 def stats_row(path, top=8):
@@ -33,6 +50,8 @@ def stats_row(path, top=8):
 
 def bench_row(path):
     d = json.loads(open(path).read().strip().splitlines()[-1])
+    if "roofline" not in d:                      # a small timing record, not a bench line
+        return "; ".join("%s %s" % (k, ("%.4g" % v) if isinstance(v, float) else v) for k, v in d.items() if not isinstance(v, (dict, list)))[:300]
     r, c = d["roofline"], d["config"]
     s = "`value` %.4f %s (%.1f ms per step, %d steps)" % (d["value"], d["unit"], d["ms_per_step"], d["steps"])
     if "value_device_vectors" in c:
@@ -87,6 +106,12 @@ def rows(rnd):
                 desc = pmc_row(f)
             elif b.endswith(".json"):
                 desc = bench_row(f)
+            elif b.endswith("_sq_counters.txt"):
+                desc = sq_row(f)
+            elif b.endswith("_pmc_summary.txt"):
+                desc = "per-kernel averages of the FETCH_SIZE / WRITE_SIZE passes (`tools/summarize_pmc.py`): the table `..._pmc.json` is reduced from"
+            elif b.endswith("pytest_gpu.log"):
+                desc = "`python -m pytest tests -m gpu -q`: " + [ln.strip() for ln in open(f) if ln.strip()][-1]
             elif b.endswith(".jsonl"):
                 desc = "%d JSON lines" % sum(1 for ln in open(f) if ln.strip())
             else:
