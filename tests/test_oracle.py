@@ -255,3 +255,68 @@ def test_threaded_kdyn_oracle_is_the_same_restatement(cost, adj):
         J1 = t.forward([B, U]); g1 = t.adjoint([B, U], adj)
         assert abs(J1 - J0) <= 1e-14 * abs(J0)
         assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[1], g0[1])
+
+
+def test_closed_form_time_steps_equal_dense_pencil_solves():
+    """The closed forms of the oracles (oracle/kdyn.py cnab_update and the nu recursion, oracle/sh23.py's divide) against a dense solve per
+    Fourier mode of the PENCIL MATRICES assembled row by row from the text of the reference's add_equation calls, stepped with Dedalus v2's
+    published CNAB1 / SBDF1 coefficient tables (oracle/pencil.py): every mode of a small grid, random complex data, non-solenoidal states
+    included — the algebraic divergence row under CNAB1 (k.B flips sign) and the k = 0 rows (X -> -X) are part of what is compared."""
+    from oracle import pencil
+    rs = np.random.RandomState(5)
+    Rm, dt = 1.7, 3e-2
+    o = KDynOracle(8, Rm=Rm, dt=dt, N_ITERS=1)
+    shp = (3, o.a, o.m, o.m)
+    V0 = rs.standard_normal(shp) + 1j * rs.standard_normal(shp)
+    F = rs.standard_normal(shp) + 1j * rs.standard_normal(shp)
+    V1 = o.cnab_update(V0, F)
+    # the adjoint's second system (variables P, nu): the oracle's recursion, FWD_Solve_KDyn.py:876-879
+    nu0 = rs.standard_normal(shp) + 1j * rs.standard_normal(shp)
+    F2 = rs.standard_normal(shp) + 1j * rs.standard_normal(shp)                  # = -F(G; B_f), the right-hand side as the equation text has it
+    nu1 = nu0 - 2. * o.K * (o.kdot(nu0) / o.k2s) + dt * o.project(F2)
+    nu1[:, o.zero] = -nu0[:, o.zero]
+    worst = 0.
+    for ix in range(o.a):
+        for iy in range(o.m):
+            for iz in range(o.m):
+                k = o.K[:, ix, iy, iz]
+                M, L = pencil.kdyn_forward_pencil(k, Rm)
+                X0 = np.concatenate([[0.], V0[:, ix, iy, iz]])                 # Pi_{n-1} does not enter: its column of M is zero and (M/dt - L/2) Pi
+                # ... does enter through L: Dedalus carries Pi as a state variable.  CNAB1's right-hand side holds -b_1 L X_{n-1}, Pi included; the
+                # closed form has no Pi history, i.e. it assumes the gradient part of the right-hand side is projected away — which is exact, because
+                # whatever Pi_{n-1} is, it adds a pure gradient i k Pi / 2 to the momentum rows and the projection in the solve removes it.  Checked
+                # by stepping with a random Pi_{n-1} as well.
+                zero = not k.any()                                             # the k = 0 pencil has its own equations ("A = 0", ...: FWD_Solve_KDyn.py:431-434) with right-hand side 0
+                Fk = np.concatenate([[0.], np.zeros(3) if zero else F[:, ix, iy, iz]])
+                for pi_prev in (0., 0.37 - 1.1j):
+                    X0[0] = pi_prev
+                    X1 = pencil.imex_step(M, L, X0, Fk, "CNAB1", dt)
+                    worst = max(worst, np.abs(X1[1:] - V1[:, ix, iy, iz]).max())
+                Ma, La = pencil.kdyn_adjoint_pencil(k, Rm)
+                Y0 = np.concatenate([[0.], V0[:, ix, iy, iz], [0.2 + 0.1j], nu0[:, ix, iy, iz]])
+                Fa = np.zeros(8, dtype=complex) if zero else np.concatenate([[0.], F[:, ix, iy, iz], [0.], F2[:, ix, iy, iz]])
+                Y1 = pencil.imex_step(Ma, La, Y0, Fa, "CNAB1", dt)
+                worst = max(worst, np.abs(Y1[1:4] - V1[:, ix, iy, iz]).max(), np.abs(Y1[5:] - nu1[:, ix, iy, iz]).max())
+    assert worst < 1e-11, worst
+    # the terminal condition of the discrete adjoint (Compatib_Cond's LBVP, FWD_Solve_KDyn.py:733-747) against oracle/kdyn.py adjoint()'s closed form
+    for cost in ("Final", "Integrated"):
+        oc = KDynOracle(8, Rm=Rm, dt=dt, N_ITERS=1, Cost_function=cost)
+        scale = (dt * oc.alpha) if cost == "Final" else oc.alpha
+        Gh = oc.project(-2. * V0) / scale
+        Gh[:, oc.zero] = 0.
+        for ix in range(oc.a):
+            for iy in range(oc.m):
+                for iz in range(oc.m):
+                    k = oc.K[:, ix, iy, iz]
+                    Lc = pencil.kdyn_compat_pencil(k, Rm, dt, cost)
+                    rhs = np.zeros(4, dtype=complex) if not k.any() else np.concatenate([[0.], -2. * V0[:, ix, iy, iz]])
+                    X = np.linalg.solve(Lc, rhs)
+                    assert np.abs(X[1:] - Gh[:, ix, iy, iz]).max() < 1e-11, (cost, ix, iy, iz)
+    s = SH23Oracle(64, dt=0.1, N_ITERS=1)
+    u0 = rs.standard_normal(s.Nc) + 1j * rs.standard_normal(s.Nc)
+    f = rs.standard_normal(s.Nc) + 1j * rs.standard_normal(s.Nc)
+    closed = (u0 / s.dt + f) / s.A                                              # oracle/sh23.py forward(): the SBDF1 step
+    for i, k in enumerate(s.k):
+        M, L = pencil.sh23_pencil(k, s.a)
+        x1 = pencil.imex_step(M, L, np.array([u0[i]]), np.array([f[i]]), "SBDF1", s.dt)
+        assert abs(x1[0] - closed[i]) < 1e-13 * max(1., abs(closed[i]))
