@@ -284,7 +284,10 @@ def cpu_topology():
             continue
     info["cgroup_cpu_quota"] = quota
     if quota is not None and quota >= 1 and len(chosen) > int(quota):
-        chosen = chosen[:int(quota)]
+        # fewer CPUs than the socket has cores: take them SPREAD over the socket (every len/quota-th physical core), not the first few — on a
+        # chiplet CPU the first 16 cores are two CCDs that share two links to the memory controllers, 16 cores over eight CCDs have eight
+        n, q = len(chosen), int(quota)
+        chosen = [chosen[(i * n) // q] for i in range(q)]
     info["cpus_used"] = chosen
     return info
 
