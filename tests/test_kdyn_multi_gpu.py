@@ -91,10 +91,45 @@ def test_single_process_multi_device_context_between_gpus(N, cost, adj, ckpt, ch
     B = kdyn.synthetic_field(G, 1) + 0.1 * np.random.RandomState(9).standard_normal(3 * G ** 3)
     U = kdyn.synthetic_field(G, 2)
     ctx = _capi.MultiContext(N, (0., 2. * np.pi), 1e-2, n, 1.3, list(range(W)), cost=cost, ckpt=ckpt)
+    assert ctx.comm_get(3) == (2 if pull == "kernel" else 1)          # the pull implementation in use is the one asked for
     J = ctx.forward([B, U]); gB, gU = ctx.adjoint(None, adj)
     o = KDynOracle(N, Rm=1.3, dt=1e-2, N_ITERS=n, Cost_function=cost)
     Jo = o.forward([B, U]); goB, goU = o.adjoint([B, U], adj)
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))      # noqa: E731
     assert abs(J - Jo) <= 1e-6 * abs(Jo) and rel(gB, goB) < 1e-6 and rel(gU, goU) < 1e-6
     assert abs(ctx.inner(B, gB) - o.inner(B, goB)) <= 1e-6 * abs(o.inner(B, goB))
+    ctx.close()
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs at least two GPUs on the node")
+def test_default_pull_between_distinct_devices_is_the_copy_engine(monkeypatch):
+    """Until the gather kernel has read a peer's HBM on hardware (this file, pull = "kernel"), distinct devices default to hipMemcpyPeerAsync
+    (ADVICE r3); ranks that share a device default to the kernel."""
+    from spheremanopt_amd import _capi
+    monkeypatch.delenv("SMO_PEER_COPY", raising=False)
+    ctx = _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 2, 1.0, [0, 1])
+    assert ctx.comm_get(3) == 1
+    ctx.close()
+    ctx = _capi.MultiContext(16, (0., 2. * np.pi), 1e-3, 2, 1.0, [0, 0])
+    assert ctx.comm_get(3) == 2
+    ctx.close()
+
+
+@pytest.mark.skipif(_ngpu() < 8, reason="needs the 8 GPUs of a node")
+@pytest.mark.parametrize("pull", ["memcpy", "kernel"])
+def test_north_star_decomposition_over_eight_gpus(pull, monkeypatch):
+    """BASELINE configs[4] over the 8 GPUs of a node in ONE process against the oracle fixture (the same check tests/test_kdyn_multi_device_gpu.py
+    runs with the box's GPU listed eight times; here the pulled bytes cross xGMI)."""
+    from conftest import GOLDEN
+    from spheremanopt_amd import _capi, kdyn
+    monkeypatch.setenv("SMO_PEER_COPY", pull)
+    gold = np.load(os.path.join(GOLDEN, "oracle_kdyn_c5_256_n2.npz"))
+    B, U = kdyn.synthetic_field(384, 1), kdyn.synthetic_field(384, 2)
+    ctx = _capi.MultiContext(256, (0., 2. * np.pi), 1e-3, 2, 1.0, list(range(8)))
+    J = ctx.forward([B, U]); g = ctx.adjoint(None, "Discrete")
+    Jo, idx = float(gold["J_Final"]), gold["idx"]
+    assert abs(J - Jo) <= 1e-6 * abs(Jo)
+    for name, v in (("gB", g[0]), ("gU", g[1])):
+        ref = gold["Final_Discrete_" + name]
+        assert np.linalg.norm(v[idx] - ref) <= 1e-6 * np.linalg.norm(ref), name
     ctx.close()
