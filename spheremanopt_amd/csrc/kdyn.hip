@@ -1514,9 +1514,15 @@ public:
     }
     // inverse side of an adjoint step carries omega only (1 field group) when B_f was kept by the forward solve, else omega and B^_idx
     int adj_groups(int idx) const { return have_ty(idx) ? 1 : 2; }
+    // one slab, one chunk: field group 0 sits at the same place of the exchange buffer whether the step carries one group or two (zs_off: row + pos,
+    // the second group tzc elements further), so the curl pass fused into the previous update serves a two-group step as well
+    bool group0_layout_is_shared() const { return cfg.world == 1 && K == 1 && !force_exchange; }
     int adj_A(int idx) {
         const int nf = adj_groups(idx);
-        if (zs_ready_adj == idx && nf == 1) { zs_ready_adj = -1; return SMO_OK; }
+        if (zs_ready_adj == idx && (nf == 1 || group0_layout_is_shared())) {
+            zs_ready_adj = -1;
+            return nf == 2 ? z_inverse(ZI_PLAIN, snap(idx), 1, 2) : SMO_OK;      // (writes the second group only)
+        }
         SMO_TRY(z_inverse(ZI_CURL, d_G, 0, nf));
         return nf == 2 ? z_inverse(ZI_PLAIN, snap(idx), 1, 2) : SMO_OK;
     }
@@ -1531,7 +1537,7 @@ public:
         // the following adjoint step (index idx - 1) starts with the inverse z pass of curl(G^): fused when that step sends one field
         // group (same buffer layout as this kernel's input) and exists at all (the continuous sweep ends at index 1, the discrete at 0)
         const int nxt = idx - 1;
-        const bool fuse = fuse_next && nxt >= (adj_cont ? 1 : 0) && adj_groups(nxt) == 1;
+        const bool fuse = fuse_next && nxt >= (adj_cont ? 1 : 0) && (adj_groups(nxt) == 1 || group0_layout_is_shared());
         SMO_TRY(z_forward(ZF_ADJ_UPDATE, d_G, d_G, snap(idx), fuse ? NX_CURL : NX_NONE));
         zs_ready_fwd = -1;
         zs_ready_adj = fuse ? nxt : -1;
